@@ -1,0 +1,384 @@
+"""CPU oracle for the mr_gan.py training path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-numpy restatement of the arithmetic that the reference builds
+through Keras 2.0.9 / Theano 0.9.0 in /root/reference/mr_gan.py:109-171 and drives from
+the loop at mr_gan.py:183-230.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it; the product path (mr-gan_amd/) never does.
+
+PARITY UNPINNED: the reference ships no tests, golden vectors, saved weights or data, and
+cannot be parsed or imported in this container (Python-2 source, Keras/Theano absent; see
+SURVEY.md section 8c).  The semantics below follow the reference source line by line plus the
+published Keras-2.0.9/Theano-0.9 behaviour recorded in SURVEY.md rows A2, A3, A5, A8; the
+only independent pins are (i) torch.autograd fp64 for every gradient
+(tests/test_oracle.py) and (ii) sklearn for the data prologue.
+
+Everything random is an explicit input (weights, z, layer noise), exactly as SURVEY 8c
+defines "identical seeds/inputs".  The noise generator restated at the bottom
+(Philox4x32-10 + Box-Muller) is the *build's* device generator, not the reference's
+MRG31k3p stream, which cannot be reproduced.
+"""
+import numpy as np
+
+# mr_gan.py:77-79, :111-128, :165 -- literals of the reference
+NOISE_SIZE = 100
+G_HIDDEN = (500, 500)
+D_HIDDEN = (1000, 500, 250, 250, 250)
+D_SIGMAS = (0.3, 0.5, 0.5, 0.5, 0.5)       # GaussianNoise before dense 1..5 (mr_gan.py:118-126)
+NUM_CLASSES = 6
+BN_EPS = 2e-5                               # mr_gan.py:112
+ADAM_LR, ADAM_B1, ADAM_B2, ADAM_EPS = 0.0006, 0.5, 0.999, 1e-8   # mr_gan.py:165 + Keras defaults
+UNLABELED_WEIGHT = 1.0                      # mr_gan.py:79
+
+
+# ----------------------------------------------------------------------------------------
+# elementary functions (Keras backend / Theano semantics)
+# ----------------------------------------------------------------------------------------
+def softplus(x):
+    # T.nnet.softplus == log1p(exp(x)), evaluated stably
+    return np.logaddexp(0.0, x).astype(x.dtype, copy=False)
+
+
+def sigmoid(x):
+    out = np.empty_like(x)
+    pos = x >= 0
+    out[pos] = 1.0 / (1.0 + np.exp(-x[pos]))
+    ex = np.exp(x[~pos])
+    out[~pos] = ex / (1.0 + ex)
+    return out
+
+
+def relu(x):
+    # T.nnet.relu(x) = 0.5*(x+|x|)
+    return np.maximum(x, 0)
+
+
+def logsumexp(x, axis=1):
+    # K.logsumexp (Theano backend) is max-shifted
+    m = np.max(x, axis=axis, keepdims=True)
+    return (m + np.log(np.sum(np.exp(x - m), axis=axis, keepdims=True))).squeeze(axis)
+
+
+# ----------------------------------------------------------------------------------------
+# parameters (Keras tensor order: SURVEY rows A2, A3)
+# ----------------------------------------------------------------------------------------
+def glorot_uniform(rng, fan_in, fan_out, dtype):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(dtype)
+
+
+def g_shapes(D, nz=NOISE_SIZE, hidden=G_HIDDEN):
+    h1, h2 = hidden
+    return [(nz, h1), (h1,), (h1,), (h1,), (h1, h2), (h2,), (h2, D), (D,)]
+
+
+def d_shapes(D, hidden=D_HIDDEN, K=NUM_CLASSES):
+    dims = (D,) + tuple(hidden) + (K,)
+    out = []
+    for i in range(len(dims) - 1):
+        out += [(dims[i], dims[i + 1]), (dims[i + 1],)]
+    return out
+
+
+def init_params(D, seed=0, dtype=np.float64, nz=NOISE_SIZE, g_hidden=G_HIDDEN, d_hidden=D_HIDDEN,
+                K=NUM_CLASSES):
+    """Keras defaults: Dense kernel glorot_uniform, bias zeros; BN gamma ones, beta zeros."""
+    rng = np.random.default_rng(seed)
+    g = []
+    for i, shp in enumerate(g_shapes(D, nz, g_hidden)):
+        if len(shp) == 2:
+            g.append(glorot_uniform(rng, shp[0], shp[1], dtype))
+        elif i == 2:                       # gamma
+            g.append(np.ones(shp, dtype))
+        else:
+            g.append(np.zeros(shp, dtype))
+    d = []
+    for shp in d_shapes(D, d_hidden, K):
+        d.append(glorot_uniform(rng, shp[0], shp[1], dtype) if len(shp) == 2 else np.zeros(shp, dtype))
+    return g, d
+
+
+# ----------------------------------------------------------------------------------------
+# generator  (mr_gan.py:110-114)
+# ----------------------------------------------------------------------------------------
+def gen_forward(g, z):
+    W1, b1, gamma, beta, W2, b2, W3, b3 = g
+    pre1 = z @ W1 + b1
+    h1 = softplus(pre1)
+    # BatchNormalization(epsilon=2e-5) at learning phase 1: batch mean, *biased* batch variance
+    mu = h1.mean(axis=0)
+    var = ((h1 - mu) ** 2).mean(axis=0)
+    rstd = 1.0 / np.sqrt(var + BN_EPS)
+    xhat = (h1 - mu) * rstd
+    hbn = gamma * xhat + beta
+    pre2 = hbn @ W2 + b2
+    h2 = softplus(pre2)
+    x = h2 @ W3 + b3
+    cache = dict(z=z, pre1=pre1, h1=h1, mu=mu, var=var, rstd=rstd, xhat=xhat, hbn=hbn, pre2=pre2, h2=h2)
+    return x, cache
+
+
+def gen_backward(g, cache, dx):
+    """dx = dLoss/d(generator output) -> grads for the 8 generator tensors (Keras order)."""
+    W1, b1, gamma, beta, W2, b2, W3, b3 = g
+    B = dx.shape[0]
+    dW3 = cache['h2'].T @ dx
+    db3 = dx.sum(axis=0)
+    dh2 = dx @ W3.T
+    dpre2 = dh2 * sigmoid(cache['pre2'])
+    dW2 = cache['hbn'].T @ dpre2
+    db2 = dpre2.sum(axis=0)
+    dhbn = dpre2 @ W2.T
+    dgamma = (dhbn * cache['xhat']).sum(axis=0)
+    dbeta = dhbn.sum(axis=0)
+    dh1 = (gamma * cache['rstd'] / B) * (B * dhbn - dbeta - cache['xhat'] * dgamma)
+    dpre1 = dh1 * sigmoid(cache['pre1'])
+    dW1 = cache['z'].T @ dpre1
+    db1 = dpre1.sum(axis=0)
+    return [dW1, db1, dgamma, dbeta, dW2, db2, dW3, db3]
+
+
+# ----------------------------------------------------------------------------------------
+# discriminator  (mr_gan.py:117-128; mid_output = first five dense layers :133)
+# ----------------------------------------------------------------------------------------
+def disc_forward(d, x, noise=None, sigmas=D_SIGMAS):
+    """noise: None (learning phase 0) or list of 5 standard-normal arrays n_l shaped like the
+    input of dense l (GaussianNoise adds sigma_l * n_l).  Returns logits, features, cache."""
+    nl = len(d) // 2
+    a = x
+    ins, pres = [], []
+    for l in range(nl - 1):
+        if noise is not None:
+            a = a + np.asarray(sigmas[l], dtype=a.dtype) * noise[l]
+        ins.append(a)
+        pre = a @ d[2 * l] + d[2 * l + 1]
+        pres.append(pre)
+        a = relu(pre)
+    feat = a                                  # disc_mid_output: post-ReLU, no noise after it
+    logits = feat @ d[-2] + d[-1]
+    return logits, feat, dict(ins=ins, pres=pres, feat=feat)
+
+
+def disc_backward(d, cache, dlogits=None, dfeat=None, want_param_grads=True):
+    """Backprop through the discriminator.  Either dlogits (D-step) or dfeat (G-step, through
+    mid_output only).  Returns (grads list or None, dLoss/dx)."""
+    nl = len(d) // 2
+    grads = [None] * len(d)
+    if dlogits is not None:
+        if want_param_grads:
+            grads[-2] = cache['feat'].T @ dlogits
+            grads[-1] = dlogits.sum(axis=0)
+        da = dlogits @ d[-2].T
+    else:
+        da = dfeat
+    for l in range(nl - 2, -1, -1):
+        dpre = da * (cache['pres'][l] > 0)
+        if want_param_grads:
+            grads[2 * l] = cache['ins'][l].T @ dpre
+            grads[2 * l + 1] = dpre.sum(axis=0)
+        da = dpre @ d[2 * l].T                # additive noise: d(in)/d(prev out) = identity
+    return (grads if want_param_grads else None), da
+
+
+# ----------------------------------------------------------------------------------------
+# losses (mr_gan.py:146-154, :161-162) with closed-form gradients
+# ----------------------------------------------------------------------------------------
+def disc_losses(l_lab, labels, l_unl, l_fake):
+    B = l_lab.shape[0]
+    lse_lab = logsumexp(l_lab)
+    loss_lab = -np.mean(l_lab[np.arange(B), labels]) + np.mean(lse_lab)
+    lse_unl = logsumexp(l_unl)
+    lse_fake = logsumexp(l_fake)
+    loss_unl = (-0.5 * np.mean(lse_unl) + 0.5 * np.mean(softplus(lse_unl))
+                + 0.5 * np.mean(softplus(lse_fake)))
+    train_err = np.mean(np.argmax(l_lab, axis=1) != labels)
+    return loss_lab, loss_unl, train_err
+
+
+def disc_loss_grads(l_lab, labels, l_unl, l_fake, unlabeled_weight=UNLABELED_WEIGHT):
+    B = l_lab.shape[0]
+    dt = l_lab.dtype
+
+    def softmax(l):
+        e = np.exp(l - l.max(axis=1, keepdims=True))
+        return e / e.sum(axis=1, keepdims=True)
+    onehot = np.zeros_like(l_lab)
+    onehot[np.arange(B), labels] = 1
+    d_lab = (softmax(l_lab) - onehot) / B
+    s_unl = sigmoid(logsumexp(l_unl))[:, None]
+    d_unl = (0.5 / l_unl.shape[0]) * softmax(l_unl) * (s_unl - 1.0) * unlabeled_weight
+    s_fake = sigmoid(logsumexp(l_fake))[:, None]
+    d_fake = (0.5 / l_fake.shape[0]) * softmax(l_fake) * s_fake * unlabeled_weight
+    return d_lab.astype(dt), d_unl.astype(dt), d_fake.astype(dt)
+
+
+def fm_loss(f_fake, f_real):
+    mom_gen = f_fake.mean(axis=0)
+    mom_real = f_real.mean(axis=0)
+    return np.mean((mom_gen - mom_real) ** 2)
+
+
+def fm_loss_grad(f_fake, f_real):
+    B, J = f_fake.shape
+    diff = f_fake.mean(axis=0) - f_real.mean(axis=0)
+    return np.broadcast_to((2.0 / (J * B)) * diff, f_fake.shape).astype(f_fake.dtype)
+
+
+# ----------------------------------------------------------------------------------------
+# Keras-2.0.9 Adam with ONE shared iteration counter for both update lists
+# ----------------------------------------------------------------------------------------
+class Adam(object):
+    def __init__(self, g, d, lr=ADAM_LR, b1=ADAM_B1, b2=ADAM_B2, eps=ADAM_EPS):
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+        self.iterations = 0
+        self.mg = [np.zeros_like(p) for p in g]
+        self.vg = [np.zeros_like(p) for p in g]
+        self.md = [np.zeros_like(p) for p in d]
+        self.vd = [np.zeros_like(p) for p in d]
+
+    def lr_t(self):
+        t = self.iterations + 1
+        return self.lr * np.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+
+    def apply(self, params, grads, which):
+        ms, vs = (self.mg, self.vg) if which == 'g' else (self.md, self.vd)
+        lr_t = self.lr_t()
+        for i, (p, g) in enumerate(zip(params, grads)):
+            dt = p.dtype
+            ms[i] = (self.b1 * ms[i] + (1.0 - self.b1) * g).astype(dt)
+            vs[i] = (self.b2 * vs[i] + (1.0 - self.b2) * g * g).astype(dt)
+            params[i] = (p - dt.type(lr_t) * ms[i] / (np.sqrt(vs[i]) + dt.type(self.eps))).astype(dt)
+        self.iterations += 1
+
+
+# ----------------------------------------------------------------------------------------
+# the three compiled functions of mr_gan.py:169-171
+# ----------------------------------------------------------------------------------------
+class MRGANOracle(object):
+    """State = Keras shared variables (weights, Adam slots, iteration counter)."""
+
+    def __init__(self, g, d, sigmas=D_SIGMAS):
+        self.g = [np.array(p) for p in g]
+        self.d = [np.array(p) for p in d]
+        self.adam = Adam(self.g, self.d)
+        self.sigmas = sigmas
+
+    # train_batch_disc([1, x_lab, labels, x_unl, noise]) -> [loss_lab, loss_unl, train_err]
+    def disc_grads(self, x_lab, labels, x_unl, z, n_lab, n_unl, n_fake):
+        x_fake, _ = gen_forward(self.g, z)
+        l_lab, _, c_lab = disc_forward(self.d, x_lab, n_lab, self.sigmas)
+        l_unl, _, c_unl = disc_forward(self.d, x_unl, n_unl, self.sigmas)
+        l_fake, _, c_fake = disc_forward(self.d, x_fake, n_fake, self.sigmas)
+        out = disc_losses(l_lab, labels, l_unl, l_fake)
+        dl_lab, dl_unl, dl_fake = disc_loss_grads(l_lab, labels, l_unl, l_fake)
+        grads = None
+        for c, dl in ((c_lab, dl_lab), (c_unl, dl_unl), (c_fake, dl_fake)):
+            g_, _ = disc_backward(self.d, c, dlogits=dl)
+            grads = g_ if grads is None else [a + b for a, b in zip(grads, g_)]
+        aux = dict(l_lab=l_lab, l_unl=l_unl, l_fake=l_fake, x_fake=x_fake)
+        return out, grads, aux
+
+    def disc_step(self, x_lab, labels, x_unl, z, n_lab, n_unl, n_fake):
+        out, grads, _ = self.disc_grads(x_lab, labels, x_unl, z, n_lab, n_unl, n_fake)
+        self.adam.apply(self.d, grads, 'd')
+        return out
+
+    # train_batch_gen([1, x_unl, noise]) -> loss_gen
+    def gen_grads(self, x_unl, z, n_fake, n_real):
+        x_fake, gc = gen_forward(self.g, z)
+        _, f_fake, c_fake = disc_forward(self.d, x_fake, n_fake, self.sigmas)
+        _, f_real, _ = disc_forward(self.d, x_unl, n_real, self.sigmas)
+        loss = fm_loss(f_fake, f_real)
+        df = fm_loss_grad(f_fake, f_real)
+        _, dx = disc_backward(self.d, c_fake, dfeat=df, want_param_grads=False)
+        grads = gen_backward(self.g, gc, dx)
+        return loss, grads, dict(f_fake=f_fake, f_real=f_real, x_fake=x_fake, dx=dx)
+
+    def gen_step(self, x_unl, z, n_fake, n_real):
+        loss, grads, _ = self.gen_grads(x_unl, z, n_fake, n_real)
+        self.adam.apply(self.g, grads, 'g')
+        return loss
+
+    # test_batch([0, x, labels]) -> err   (noise layers are identity at phase 0)
+    def predict_logits(self, x):
+        return disc_forward(self.d, x, None)[0]
+
+    def test_error(self, x, labels):
+        return np.mean(np.argmax(self.predict_logits(x), axis=1) != labels)
+
+
+# ----------------------------------------------------------------------------------------
+# data prologue and epoch staging (mr_gan.py:96-107, :189-202) -- restated for the host tests
+# ----------------------------------------------------------------------------------------
+def standard_scale(X_train, X_test):
+    """sklearn StandardScaler: per-feature mean and *population* std; zero std -> scale 1."""
+    mu = X_train.mean(axis=0)
+    sd = X_train.std(axis=0)
+    sd = np.where(sd == 0.0, 1.0, sd)
+    return (X_train - mu) / sd, (X_test - mu) / sd
+
+
+def select_labeled(X_train, y_train, n_lab, K=NUM_CLASSES):
+    # mr_gan.py:102-103 : first n_lab rows of each class, classes concatenated in order
+    x = np.concatenate([X_train[y_train == j][:n_lab] for j in range(K)], axis=0)
+    y = np.concatenate([[j] * n_lab for j in range(K)], axis=0)
+    return x, y
+
+
+def tiled_permutation(rng_perm, n_pool, n_total):
+    """mr_gan.py:189: floor(n_total/n_pool) permutations of range(n_pool) followed by a
+    permutation of range(n_total % n_pool) -- NOT a random subset: the tail only touches the
+    first n_total % n_pool rows of the (class-sorted) pool.  rng_perm(n) -> permutation."""
+    parts = [rng_perm(n_pool) for _ in range(n_total // n_pool)] + [rng_perm(n_total % n_pool)]
+    return np.concatenate(parts).astype(np.int64)
+
+
+# ----------------------------------------------------------------------------------------
+# The build's device noise generator, restated: Philox4x32-10 keyed by the seed, counter =
+# (column, row>>2, site*256+segment, sub-step); one call yields the four normals of rows
+# 4q..4q+3 at one column through two Box-Muller pairs.
+# ----------------------------------------------------------------------------------------
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+SITE_Z = 16     # generator input z; sites 0..4 are the GaussianNoise layers before dense 1..5
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3)]
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    m32 = np.uint64(0xFFFFFFFF)
+    with np.errstate(over='ignore'):
+        for _ in range(10):
+            p0 = _M0 * c0.astype(np.uint64)
+            p1 = _M1 * c2.astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & m32).astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & m32).astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32(k0 + _W0)
+            k1 = np.uint32(k1 + _W1)
+    return c0, c1, c2, c3
+
+
+def _u01(x):
+    # ((x>>9)+0.5) * 2^-23 : exactly representable in fp32, strictly inside (0,1)
+    return ((x >> np.uint32(9)).astype(np.float64) + 0.5) * (1.0 / 8388608.0)
+
+
+def device_normal(seed, site, seg, step, rows, cols, row0=0, dtype=np.float64):
+    """Standard normals [rows, cols] exactly as the HIP kernels draw them (up to the ulp-level
+    error of the device's log2/sqrt/sin/cos).  row0 = global index of the first row within its
+    segment (multiple of 4) -- used by data-parallel ranks."""
+    assert row0 % 4 == 0
+    nq = (rows + 3) // 4
+    q = (np.arange(nq, dtype=np.uint32) + np.uint32(row0 // 4))[:, None]
+    c = np.arange(cols, dtype=np.uint32)[None, :]
+    x0, x1, x2, x3 = philox4x32_10(c, q, np.uint32(site * 256 + seg), np.uint32(step),
+                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    out = np.empty((nq * 4, cols), dtype=np.float64)
+    for j, (a, b) in enumerate(((x0, x1), (x2, x3))):
+        r = np.sqrt(-2.0 * np.log(_u01(a)))
+        th = 2.0 * np.pi * _u01(b)
+        out[2 * j::4] = r * np.cos(th)
+        out[2 * j + 1::4] = r * np.sin(th)
+    return out[:rows].astype(dtype)

@@ -1,0 +1,153 @@
+"""Pins for the CPU oracle (oracle/mrgan_oracle.py).
+
+The reference holds no golden vectors (parity unpinned), so the oracle's closed-form
+backward passes are pinned against torch.autograd in fp64 on the same forward expressions as
+mr_gan.py:110-154, its Adam against a literal transcription of the Keras-2.0.9 formula, and the
+data prologue against sklearn.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mrgan_oracle as O
+
+
+def _rand_problem(D=24, B=10, seed=3):
+    rng = np.random.default_rng(seed)
+    g, d = O.init_params(D, seed=seed)
+    # non-trivial biases / BN affine so every gradient path is exercised
+    g = [p + 0.05 * rng.standard_normal(p.shape) for p in g]
+    d = [p + 0.05 * rng.standard_normal(p.shape) for p in d]
+    x_lab = rng.standard_normal((B, D))
+    x_unl = rng.standard_normal((B, D))
+    labels = rng.integers(0, 6, B)
+    z = rng.standard_normal((B, O.NOISE_SIZE))
+    dims = (D,) + O.D_HIDDEN
+    noise = lambda: [rng.standard_normal((B, dims[l])) for l in range(5)]
+    return g, d, x_lab, labels, x_unl, z, noise(), noise(), noise()
+
+
+def _t(a):
+    return torch.tensor(a, dtype=torch.float64, requires_grad=True)
+
+
+def _torch_gen(g, z):
+    W1, b1, gamma, beta, W2, b2, W3, b3 = g
+    h = torch.nn.functional.softplus(z @ W1 + b1)
+    mu = h.mean(0)
+    var = ((h - mu) ** 2).mean(0)
+    h = gamma * (h - mu) / torch.sqrt(var + O.BN_EPS) + beta
+    h = torch.nn.functional.softplus(h @ W2 + b2)
+    return h @ W3 + b3
+
+
+def _torch_disc(d, x, noise, upto_feat=False):
+    a = x
+    for l in range(5):
+        a = a + O.D_SIGMAS[l] * torch.tensor(noise[l])
+        a = torch.relu(a @ d[2 * l] + d[2 * l + 1])
+    if upto_feat:
+        return a
+    return a @ d[10] + d[11]
+
+
+def test_disc_step_grads_match_autograd():
+    g, d, x_lab, labels, x_unl, z, n1, n2, n3 = _rand_problem()
+    orc = O.MRGANOracle(g, d)
+    (ll, lu, err), grads, _ = orc.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3)
+    tg = [_t(p) for p in g]
+    td = [_t(p) for p in d]
+    l_lab = _torch_disc(td, torch.tensor(x_lab), n1)
+    l_unl = _torch_disc(td, torch.tensor(x_unl), n2)
+    l_fake = _torch_disc(td, _torch_gen(tg, torch.tensor(z)), n3)
+    B = x_lab.shape[0]
+    lab = torch.tensor(labels)
+    sp = torch.nn.functional.softplus
+    # mr_gan.py:146-149
+    loss_lab = -l_lab[torch.arange(B), lab].mean() + torch.logsumexp(l_lab, 1).mean()
+    loss_unl = (-0.5 * torch.logsumexp(l_unl, 1).mean() + 0.5 * sp(torch.logsumexp(l_unl, 1)).mean()
+                + 0.5 * sp(torch.logsumexp(l_fake, 1)).mean())
+    (loss_lab + loss_unl).backward()
+    assert abs(ll - loss_lab.item()) < 1e-12 and abs(lu - loss_unl.item()) < 1e-12
+    for a, b in zip(grads, td):
+        np.testing.assert_allclose(a, b.grad.numpy(), rtol=1e-9, atol=1e-12)
+    assert err == np.mean(l_lab.detach().numpy().argmax(1) != labels)
+
+
+def test_gen_step_grads_match_autograd():
+    g, d, x_lab, labels, x_unl, z, n1, n2, _ = _rand_problem(seed=5)
+    orc = O.MRGANOracle(g, d)
+    loss, grads, _ = orc.gen_grads(x_unl, z, n1, n2)
+    tg = [_t(p) for p in g]
+    td = [_t(p) for p in d]
+    f_fake = _torch_disc(td, _torch_gen(tg, torch.tensor(z)), n1, upto_feat=True)
+    f_real = _torch_disc(td, torch.tensor(x_unl), n2, upto_feat=True)
+    tl = ((f_fake.mean(0) - f_real.mean(0)) ** 2).mean()      # mr_gan.py:152-154
+    tl.backward()
+    assert abs(loss - tl.item()) < 1e-14
+    for a, b in zip(grads, tg):
+        np.testing.assert_allclose(a, b.grad.numpy(), rtol=1e-8, atol=1e-13)
+
+
+def test_adam_shared_counter_and_formula():
+    # Keras 2.0.9 Adam.get_updates: t = iterations + 1 on ONE counter shared by both lists
+    g, d, x_lab, labels, x_unl, z, n1, n2, n3 = _rand_problem(seed=7)
+    orc = O.MRGANOracle(g, d)
+    d0 = [p.copy() for p in orc.d]
+    g0 = [p.copy() for p in orc.g]
+    _, gd, _ = orc.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3)
+    orc.disc_step(x_lab, labels, x_unl, z, n1, n2, n3)
+    lr1 = O.ADAM_LR * np.sqrt(1 - 0.999 ** 1) / (1 - 0.5 ** 1)
+    for p0, p1, gr in zip(d0, orc.d, gd):
+        m = 0.5 * gr
+        v = 0.001 * gr * gr
+        np.testing.assert_allclose(p1, p0 - lr1 * m / (np.sqrt(v) + 1e-8), rtol=1e-12, atol=1e-15)
+    _, gg, _ = orc.gen_grads(x_unl, z, n1, n2)
+    orc.gen_step(x_unl, z, n1, n2)
+    lr2 = O.ADAM_LR * np.sqrt(1 - 0.999 ** 2) / (1 - 0.5 ** 2)       # t = 2 for the first G step
+    for p0, p1, gr in zip(g0, orc.g, gg):
+        m = 0.5 * gr
+        v = 0.001 * gr * gr
+        np.testing.assert_allclose(p1, p0 - lr2 * m / (np.sqrt(v) + 1e-8), rtol=1e-12, atol=1e-15)
+    assert orc.adam.iterations == 2
+
+
+def test_standard_scale_matches_sklearn():
+    from sklearn import preprocessing
+    rng = np.random.default_rng(0)
+    Xtr = rng.standard_normal((60, 7)) * 3 + 1
+    Xtr[:, 3] = 2.0                      # constant feature
+    Xte = rng.standard_normal((11, 7))
+    sc = preprocessing.StandardScaler()
+    a = sc.fit_transform(Xtr)
+    b = sc.transform(Xte)
+    a2, b2 = O.standard_scale(Xtr, Xte)
+    np.testing.assert_allclose(a, a2, atol=1e-12)
+    np.testing.assert_allclose(b, b2, atol=1e-12)
+
+
+def test_tiled_permutation_tail_quirk():
+    rng = np.random.RandomState(1)
+    inds = O.tiled_permutation(rng.permutation, 480, 6000)
+    assert inds.shape == (6000,)
+    assert sorted(inds[:480]) == list(range(480))
+    assert sorted(inds[5760:]) == list(range(240))      # tail touches only the first 240 pool rows
+
+
+def test_philox_known_answer():
+    # Random123 known-answer vectors for philox4x32-10
+    out = O.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(x) for x in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    ff = 0xFFFFFFFF
+    out = O.philox4x32_10(ff, ff, ff, ff, ff, ff)
+    assert [int(x) for x in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    out = O.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+    assert [int(x) for x in out] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_device_normal_moments():
+    n = O.device_normal(seed=1234, site=1, seg=2, step=7, rows=2048, cols=256)
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1.0) < 0.01
+    # row-offset consistency (data-parallel shards draw the same global stream)
+    n2 = O.device_normal(seed=1234, site=1, seg=2, step=7, rows=1024, cols=256, row0=1024)
+    np.testing.assert_array_equal(n[1024:], n2)
