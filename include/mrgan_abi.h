@@ -1,0 +1,148 @@
+/* libmrgan_hip -- C ABI of the MI355X-native mr_gan training path.
+ *
+ * Drop-in boundary: the three Theano-compiled callables of the reference,
+ *     train_batch_disc([phase, x_lab, labels, x_unl, noise]) -> [loss_lab, loss_unl, train_err]   (mr_gan.py:169)
+ *     train_batch_gen ([phase, x_unl, noise])               -> loss_gen                           (mr_gan.py:170)
+ *     test_batch      ([phase, x_lab, labels])              -> test_err                           (mr_gan.py:171)
+ * plus the state they close over (Keras shared variables: weights of mr_gan.py:110-128, the two Adam update
+ * lists and their single iteration counter, mr_gan.py:165-167).
+ *
+ * Conventions: every function returns 0 on success and a negative code on failure; the message is available
+ * from mrgan_last_error() (thread-local).  Nothing throws across the ABI.  All pointers named *_dev are device
+ * pointers (HBM); the caller owns inputs and outputs, the handle owns weights, optimiser state and workspace.
+ * Calls are asynchronous on `stream` unless a host output pointer is passed (then the call synchronises the
+ * stream before returning).  One handle per device; a handle is not thread-safe; no global state.
+ * No torch types appear here: the Python host passes tensor.data_ptr() and the raw hipStream_t.
+ */
+#ifndef MRGAN_ABI_H
+#define MRGAN_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mrgan_handle mrgan_handle;
+typedef void* mrgan_stream;               /* hipStream_t */
+
+enum { MRGAN_F32 = 0, MRGAN_BF16 = 1 };   /* arithmetic of the dense stacks: fp32 MFMA (parity) / bf16 MFMA (speed) */
+enum { MRGAN_NET_G = 0, MRGAN_NET_D = 1 };
+enum {
+    MRGAN_FLAG_SYNC_STATS = 1,   /* batch statistics (BN, feature-matching moments) are exchanged between phases   */
+    MRGAN_FLAG_FLAT_GRADS = 2,   /* gradients are reduced into the flat buffers; Adam runs as its own phase        */
+    MRGAN_FLAG_GRAPH      = 4    /* mrgan_train_pair replays a captured hipGraph (stream-mode arguments only)      */
+};
+
+/* Hyper-parameters are literals inside mr_gan() in the reference (mr_gan.py:77-79, :111-128, :165);
+ * mrgan_default_config() fills exactly those values. */
+typedef struct mrgan_config {
+    int32_t d_in;             /* D = X_train.shape[1]                                  (mr_gan.py:114, :117)  */
+    int32_t batch;            /* rows per sub-batch on THIS rank; reference batchSize = 50      (mr_gan.py:78) */
+    int32_t noise_size;       /* 100                                                            (mr_gan.py:77) */
+    int32_t g_hidden[2];      /* 500, 500                                                  (mr_gan.py:111-113) */
+    int32_t d_hidden[5];      /* 1000, 500, 250, 250, 250                                  (mr_gan.py:119-127) */
+    int32_t num_classes;      /* 6 materials; the fake class is the implicit zero logit        (mr_gan.py:128) */
+    int32_t dtype;            /* MRGAN_F32 | MRGAN_BF16 */
+    float sigma[5];           /* GaussianNoise std before discriminator dense 1..5: .3 .5 .5 .5 .5 (:118-126)  */
+    float lr, beta1, beta2, adam_eps;      /* Adam(lr=0.0006, beta_1=0.5), Keras defaults         (mr_gan.py:165) */
+    float bn_eps;             /* 2e-5                                                          (mr_gan.py:112) */
+    float unlabeled_weight;   /* 1                                                              (mr_gan.py:79) */
+    uint64_t seed;            /* key of the device Philox streams (layer noise, z) */
+    int32_t rank, world;      /* data-parallel position: global batch = batch*world, noise rows offset by rank*batch */
+    int32_t flags;
+    int32_t reserved;
+} mrgan_config;
+
+int mrgan_default_config(mrgan_config* cfg, int32_t d_in, int32_t batch);
+
+/* Workspace: all device memory of a handle is one block.  Pass workspace_dev = NULL to let the library
+ * hipMalloc it, or allocate `bytes` yourself (e.g. a torch uint8 tensor) to be able to alias sub-regions. */
+int mrgan_workspace_bytes(const mrgan_config* cfg, size_t* bytes);
+int mrgan_create(const mrgan_config* cfg, void* workspace_dev, size_t bytes, mrgan_stream stream, mrgan_handle** out);
+int mrgan_destroy(mrgan_handle* h);
+const char* mrgan_last_error(void);
+
+/* Weights in Keras order.  G: W1 b1 gamma beta W2 b2 W3 b3 (generator.trainable_weights, mr_gan.py:131);
+ * D: (W,b) x 6 (discriminator.trainable_weights, mr_gan.py:132).  Dense fp32 [rows, cols] row-major. */
+int mrgan_num_tensors(const mrgan_handle* h, int net, int* n);
+int mrgan_tensor_shape(const mrgan_handle* h, int net, int idx, int* rows, int* cols);
+int mrgan_set_weights(mrgan_handle* h, int net, int idx, const float* src_dev, mrgan_stream stream);
+int mrgan_get_weights(mrgan_handle* h, int net, int idx, float* dst_dev, mrgan_stream stream);
+/* which: 0 = Adam m, 1 = Adam v, 2 = last flat gradient (only meaningful with MRGAN_FLAG_FLAT_GRADS) */
+int mrgan_get_slot(mrgan_handle* h, int net, int idx, int which, float* dst_dev, mrgan_stream stream);
+int mrgan_set_slot(mrgan_handle* h, int net, int idx, int which, const float* src_dev, mrgan_stream stream);
+int mrgan_get_iterations(mrgan_handle* h, mrgan_stream stream, uint32_t* iterations_host);
+int mrgan_set_iterations(mrgan_handle* h, uint32_t iterations, uint32_t batch_counter, mrgan_stream stream);
+
+/* train_batch_disc (mr_gan.py:169, :207).  x_* are fp32 row-major with pitch ld_x; if idx_* is non-NULL row r
+ * of the batch is x[idx[r]] (device-side gather from a resident pool, replacing the host slicing of
+ * mr_gan.py:190-195, :207).  z_dev = NULL draws z on the device.  stream_mode = 1: idx/labels/z address whole-epoch
+ * streams and the batch offset comes from the device batch counter (advanced by the generator step). */
+typedef struct mrgan_disc_args {
+    const float* x_lab_dev; const int32_t* idx_lab_dev; const int32_t* labels_dev;
+    const float* x_unl_dev; const int32_t* idx_unl_dev;
+    const float* z_dev;
+    int64_t ld_x_lab, ld_x_unl;
+    int32_t stream_mode, reserved;
+} mrgan_disc_args;
+
+/* train_batch_gen (mr_gan.py:170, :213) */
+typedef struct mrgan_gen_args {
+    const float* x_unl_dev; const int32_t* idx_unl_dev;
+    const float* z_dev;
+    int64_t ld_x_unl;
+    int32_t stream_mode, reserved;
+} mrgan_gen_args;
+
+/* Phases exist for data-parallel drivers: a statistic or gradient exchange (RCCL all-reduce issued by the
+ * host on the regions below) sits between consecutive phases.  Single-GPU callers pass (0, -1) = everything. */
+enum { MRGAN_D_GEN = 0, MRGAN_D_MAIN = 1, MRGAN_D_ADAM = 2, MRGAN_D_NPHASES = 3 };
+enum { MRGAN_G_GEN = 0, MRGAN_G_FEAT = 1, MRGAN_G_BWD = 2, MRGAN_G_TAIL = 3, MRGAN_G_ADAM = 4, MRGAN_G_NPHASES = 5 };
+/* out3_host (optional): loss_lab, loss_unl, train_err -- the outputs of train_batch_disc */
+int mrgan_disc_step(mrgan_handle* h, const mrgan_disc_args* a, int phase_first, int phase_last,
+                    float* out3_host, mrgan_stream stream);
+/* out1_host (optional): loss_gen */
+int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int phase_first, int phase_last,
+                   float* out1_host, mrgan_stream stream);
+/* one iteration of the hot loop (mr_gan.py:204-213): D step then G step */
+int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_args* g, mrgan_stream stream);
+
+/* regions a data-parallel host all-reduces (sum) between phases; fp32 */
+enum {
+    MRGAN_REGION_BN_STATS = 0,   /* after *_GEN : [2][N1p]  sum h, sum h^2 of the generator BatchNorm input      */
+    MRGAN_REGION_FM_MOMENTS = 1, /* after G_FEAT: [2][Fp]   sum_b f(fake), sum_b f(real)                         */
+    MRGAN_REGION_BN_BWD = 2,     /* after G_BWD : [2][N1p]  sum dy, sum dy*xhat                                  */
+    MRGAN_REGION_GRAD_D = 3,     /* after D_MAIN: flat padded gradients of the 12 D tensors + 4 scalars          */
+    MRGAN_REGION_GRAD_G = 4,     /* after G_TAIL: flat padded gradients of the 8 G tensors + 4 scalars           */
+    MRGAN_REGION_WORKSPACE = 5
+};
+int mrgan_region(mrgan_handle* h, int region, void** ptr_dev, size_t* bytes);
+
+/* test_batch (mr_gan.py:171, :221-222, :230): learning phase 0, discriminator only.
+ * err_host = mean(argmax(logits) != labels) over the n rows. */
+int mrgan_eval_error(mrgan_handle* h, const float* x_dev, const int32_t* idx_dev, int64_t ld_x,
+                     const int32_t* labels_dev, int64_t n, float* err_host, mrgan_stream stream);
+/* logits_dev: fp32 [n, num_classes] */
+int mrgan_predict_logits(mrgan_handle* h, const float* x_dev, const int32_t* idx_dev, int64_t ld_x, int64_t n,
+                         float* logits_dev, mrgan_stream stream);
+
+/* epoch metrics accumulated on the device (mr_gan.py:208-210 accumulate on the host and force a sync per step):
+ * out8_host = sum loss_lab, sum loss_unl, sum train_err, sum loss_gen, last loss_lab, last loss_unl, last err,
+ * last loss_gen.  reset != 0 zeroes the sums afterwards. */
+int mrgan_read_metrics(mrgan_handle* h, float* out8_host, int reset, mrgan_stream stream);
+
+/* diagnostics used by the parity tests */
+int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,
+                      float* out_dev, mrgan_stream stream);
+int mrgan_debug_tr_probe(uint16_t* out512_dev, mrgan_stream stream);
+/* raw GEMM entry for kernel-level parity tests: op 0 = Y = act(X W + b), 1 = dX = dY W^T, 2 = dW = X^T dY.
+ * fp32 device buffers in and out (converted internally when dtype = bf16). */
+int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a_dev, const float* b_dev, const float* bias_dev,
+                     int act, int splits, float* out_dev, mrgan_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+// Argument blocks + launchers for the non-GEMM kernels of the mr_gan training path.
+#pragma once
+#include "common.h"
+
+namespace mrgan {
+
+constexpr int KMAX = 8;            // classes are padded to 8 logits (reference: 6 materials, mr_gan.py:80)
+constexpr int HEAD_ROWS = 64;      // rows per loss-head block
+
+// ---- staging: rows of the (scaled) data matrix -> noisy discriminator input; z -> generator input ----
+struct StageSeg {
+    const float* src; const int32_t* idx; long ld;   // row r comes from src[(idx ? idx[o+r] : o+r) * ld + c]
+    int rows, cols, cols_pad;
+    void* out; int ldo;                             // T [rows][ldo]; columns >= cols are zero-filled
+    float sigma; uint32_t site, seg;
+    int gen;                                        // 1: out = N(0,1) only (z drawn on device), src ignored
+    int stream;                                     // 1: o = batch * rows from the device batch counter
+};
+struct StageArgs {
+    StageSeg s[4]; int nseg;
+    uint64_t seed; uint32_t row0;
+    const DevState* cur; DevState* next; int advance_batch;
+    float lr, b1, b2;
+};
+int launch_stage(int bf16, const StageArgs& a, hipStream_t s);
+
+// ---- BatchNorm (batch statistics, biased variance; mr_gan.py:112) ----
+struct BnApplyArgs {
+    const void* h; void* out; int ld; int rows; int cols;      // cols = logical width
+    const float* cs1; const float* cs2; int npart; int ldcs;   // column partial sums of h and h^2
+    float count, eps;                                          // global batch size
+    const float* gamma; const float* beta;
+    float* mu; float* rstd;                                    // saved for the backward pass
+};
+int launch_bn_apply(int bf16, const BnApplyArgs& a, hipStream_t s);
+
+struct BnBwdArgs {
+    const void* dy; const void* h; void* dpre; int ld; int rows; int cols;
+    const float* cs1; const float* cs2; int npart; int ldcs;   // sum(dy), sum(dy*xhat) partials
+    float count;
+    const float* gamma; const float* mu; const float* rstd;
+    float* db_part; int rows_per_block;                        // column sums of dpre per row block
+};
+int launch_bn_bwd(int bf16, const BnBwdArgs& a, hipStream_t s);
+
+// ---- loss head (mr_gan.py:128, :146-149, :161-162): last dense + losses + their gradients ----
+enum { HEAD_LAB = 0, HEAD_UNL = 1, HEAD_FAKE = 2, HEAD_EVAL = 3, HEAD_LOGITS = 4 };
+struct HeadArgs {
+    const void* f; long f_bs; int ldf;         // features [seg][rows][ldf]
+    int rows, nseg, seg_kind[3];
+    int feat, feat_valid, classes;             // padded / logical feature width, number of classes
+    const float* w; int ldw; const float* b;   // last dense: w[feat][ldw], b[classes]
+    const int32_t* labels;                     // [rows] (stream mode: offset by batch*rows)
+    const DevState* st; int labels_stream;
+    float inv_count, unl_weight;               // 1/(global batch), mr_gan.py:79
+    float* logits; long logits_bs;             // optional [seg][rows][KMAX]
+    void* dpre; long dpre_bs; int ldd;         // dL/d(pre-activation of the feature layer), T
+    float* dw_part; float* db_part;            // [blk][feat][KMAX], [blk][KMAX]
+    float* dbf_part; int ldbf;                 // [blk][ldbf] column sums of dpre (bias grad of the feature layer)
+    float* loss_part;                          // [blk][4] : sum loss_lab, sum loss_unl terms, sum err, 0
+    int* err_count;                            // HEAD_EVAL: integer count of argmax != label
+};
+int launch_head(int bf16, const HeadArgs& a, hipStream_t s);
+int init_kernel_attributes();
+
+// ---- feature matching (mr_gan.py:152-154) ----
+struct FmArgs {
+    const float* cs; int npart_fake, npart_real, ldcs;   // column partial sums of f: fake rows first, then real
+    float count; int feat, feat_valid;
+    const uint32_t* mask; int ldm;                        // relu mask of the fake rows' feature layer
+    void* dpre; int ldd; int rows; int rows_per_block;
+    float* loss_out; float* accum;                        // step scalar + epoch accumulator (block 0 only)
+};
+int launch_fm(int bf16, const FmArgs& a, hipStream_t s);
+
+// ---- collapse per-row-tile partial sums to one row (data-parallel statistic exchange) ----
+int launch_colsum_finalize(const float* part, int npart, int ld, int n, float* out, hipStream_t s);
+
+// ---- multi-tensor Adam (Keras 2.0.9 formula, mr_gan.py:165-167) ----
+struct AdamTile {
+    float* p; float* m; float* v;
+    const float* g; int nslab; long slab_stride;       // gradient = sum of nslab slabs
+    float* flat;                                       // flat gradient buffer (tile origin)
+    __bf16* w16; __bf16* wt16;                         // bf16 copies [K][N] and [N][K] (null for fp32 / 1-D)
+    int ld, ldt;                                       // row pitch of p/m/v/g/w16 ; of wt16
+    int rows, cols;                                    // tile extent (<= 64 x 64)
+};
+enum { ADAM_FUSED = 0, ADAM_REDUCE_ONLY = 1, ADAM_FROM_FLAT = 2 };
+struct AdamArgs {
+    const AdamTile* tiles; int ntiles; int mode;
+    float b1, b2, eps;
+    const DevState* st;
+    // metrics finish (block 0): loss partials of this sub-step -> step_out[0..2] and epoch accumulators
+    const float* loss_part; int nloss_part; float inv_rows; float* step_out; float* accum;
+    float* flat_tail;                                  // 4 floats after the flat gradients (travel with the all-reduce)
+};
+int launch_adam(const AdamArgs& a, hipStream_t s);
+
+int launch_noise_debug(uint64_t seed, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,
+                       float* out, hipStream_t s);
+
+}  // namespace mrgan

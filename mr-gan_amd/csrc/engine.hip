@@ -1,0 +1,965 @@
+// Engine behind include/mrgan_abi.h: workspace layout in HBM, the launch sequence of one discriminator
+// sub-step and one generator sub-step (mr_gan.py:204-213), evaluation, and the C ABI itself.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/mrgan_abi.h"
+#include "aux_kernels.h"
+#include "gemm.h"
+
+using namespace mrgan;
+
+namespace mrgan {
+int launch_tr_probe(unsigned short* out, hipStream_t s);
+}
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                               \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) return fail(-10, "%s failed: %s", #x, hipGetErrorString(e_));     \
+    } while (0)
+#define CHK(x)                                                          \
+    do {                                                                \
+        int r_ = (x);                                                   \
+        if (r_ != 0) return r_ < -9 ? r_ : fail(r_, "launch failed (%d) at %s:%d", r_, __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int PADW = 64;       // every feature dimension is padded to a multiple of 64 (zero-filled)
+constexpr int SEG_ALIGN = 128; // segment row stride is a multiple of the GEMM block tile
+
+struct Tensor {                // one trainable tensor (padded fp32 master + Adam slots)
+    int rows, cols;            // logical (1-D: rows = 1)
+    int prow, pcol;            // padded
+    float *p, *m, *v;
+    __bf16 *w16, *wt16;
+    float* flat;               // position inside the flat gradient buffer
+    const float* g; int nslab; long slab_stride;      // fused-mode gradient source
+};
+
+struct Dense {
+    int K, N, Kp, Np, act;
+    Tensor *W, *b;
+    float* slabs; int splits;   // weight-gradient slabs [nseg*splits][Kp][Np]
+};
+
+struct Arena {
+    char* base = nullptr; size_t off = 0, cap = 0;
+    template <typename T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace
+
+struct mrgan_handle {
+    mrgan_config cfg;
+    bool bf16, sync_stats, flat_grads, own_ws;
+    int es;                               // activation element size
+    int B, S, tiles_m, Bg;                // local batch, segment stride, row tiles per segment, global batch
+    int Dp, nzp, Fp, F;                   // padded input / z / feature widths
+    char* ws; size_t ws_bytes;
+
+    std::vector<Tensor> gt, dt;           // Keras order
+    Dense g[3], d[6];
+
+    DevState* state;                      // [2]
+    int cur;                              // host mirror of the live slot
+    float* step_out;                      // [4]
+    float* accum;                         // [4]
+    int* err_count;
+    float *flat_d, *flat_g; size_t flat_d_n, flat_g_n;
+    float *r_bn_stats, *r_fm, *r_bn_bwd;
+
+    // activations (T = float | __bf16)
+    void *zbuf, *h1, *hbn, *h2;
+    void* xin[5]; void* feat; uint32_t* mask[5]; int ldm[5];
+    void* dpre[5];
+    void *dxfake, *dpre2g, *dhbn, *dpre1g;
+    float* logits;
+    float *bn_mu, *bn_rstd;
+    // partial sums
+    float *cs_bn1, *cs_bn2, *cs_db[4], *cs_f, *cs_db3g, *cs_db2g, *cs_dbeta, *cs_dgamma, *db1g_part;
+    float *dw6_part, *db6_part, *dbf_part, *loss_part;
+    int nblk_head, bnb_rows_per_block, bnb_blocks;
+    AdamTile *tiles_g_dev, *tiles_d_dev; int ntiles_g, ntiles_d;
+
+    // graph replay of (D step, G step)
+    hipGraphExec_t graph_exec; bool graph_ready; int graph_cur; mrgan_disc_args graph_d; mrgan_gen_args graph_g;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels (weights in/out, debug GEMM staging)
+// ------------------------------------------------------------------------------------------------
+__global__ void refresh_bf16_kernel(const float* p, __bf16* w16, __bf16* wt16, int prow, int pcol) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= prow || c >= pcol) return;
+    const __bf16 v = (__bf16)p[(long)r * pcol + c];
+    if (w16) w16[(long)r * pcol + c] = v;
+    if (wt16) wt16[(long)c * prow + r] = v;
+}
+template <typename T>
+__global__ void convert_kernel(const float* src, long lds, T* dst, long ldd, int rows, int cols, int prow, int pcol, int transpose) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= prow || c >= pcol) return;
+    const float v = (r < rows && c < cols) ? src[(long)r * lds + c] : 0.f;
+    if (transpose) dst[(long)c * ldd + r] = Elem<T>::from_f32(v);
+    else dst[(long)r * ldd + c] = Elem<T>::from_f32(v);
+}
+template <typename T>
+__global__ void to_f32_kernel(const T* src, long lds, float* dst, long ldd, int rows, int cols) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= rows || c >= cols) return;
+    dst[(long)r * ldd + c] = Elem<T>::to_f32(src[(long)r * lds + c]);
+}
+__global__ void sum_slabs_kernel(const float* slabs, int nslab, long stride, long n, float* out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+    out[i] = s;
+}
+__global__ void init_state_kernel(DevState* st, uint32_t iter, uint32_t batch, float lr, float b1, float b2) {
+    DevState s;
+    s.iter = iter; s.batch = batch; s.pad = 0;
+    const double t = (double)iter + 1.0;
+    s.lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    st[0] = s; st[1] = s;
+}
+
+inline dim3 grid2d(int prow, int pcol) { return dim3(ceil_div(pcol, 64), ceil_div(prow, 4)); }
+
+// ------------------------------------------------------------------------------------------------
+// layout
+// ------------------------------------------------------------------------------------------------
+int pad64(int x) { return (int)round_up(x, PADW); }
+
+int choose_splits(int Kp, int Np, int nseg, int rows) {
+    const int tiles = ceil_div(Kp, 128) * ceil_div(Np, 128) * nseg;
+    int s = 320 / tiles;                       // aim for ~1-1.25 waves of 256 CUs
+    s = std::min(s, ceil_div(rows, 256));       // keep >= 256 reduction rows per split
+    return std::max(1, std::min(s, 16));
+}
+
+int validate(const mrgan_config& c) {
+    if (c.d_in < 1 || c.batch < 1) return fail(-1, "d_in and batch must be positive");
+    if (c.num_classes < 2 || c.num_classes > KMAX) return fail(-1, "num_classes must be in [2,%d]", KMAX);
+    if (pad64(c.d_hidden[4]) > 256) return fail(-1, "feature layer wider than 256 is not supported by the fused loss head");
+    if (c.dtype != MRGAN_F32 && c.dtype != MRGAN_BF16) return fail(-1, "unknown dtype");
+    if (c.world < 1 || c.rank < 0 || c.rank >= c.world) return fail(-1, "bad rank/world");
+    if (c.world > 1 && (c.batch % 4) != 0) return fail(-1, "data-parallel shards need batch %% 4 == 0 (noise row groups)");
+    if (c.world > 1 && (c.flags & (MRGAN_FLAG_FLAT_GRADS)) == 0) return fail(-1, "world > 1 requires MRGAN_FLAG_FLAT_GRADS");
+    for (int i = 0; i < 5; ++i) if (c.d_hidden[i] < 1) return fail(-1, "bad d_hidden");
+    if (c.g_hidden[0] < 1 || c.g_hidden[1] < 1 || c.noise_size < 1) return fail(-1, "bad generator sizes");
+    return 0;
+}
+
+// carve the workspace; with base == nullptr only computes the size
+int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
+    const mrgan_config& c = h->cfg;
+    h->bf16 = c.dtype == MRGAN_BF16;
+    h->es = h->bf16 ? 2 : 4;
+    h->sync_stats = (c.flags & MRGAN_FLAG_SYNC_STATS) != 0;
+    h->flat_grads = (c.flags & MRGAN_FLAG_FLAT_GRADS) != 0;
+    h->B = c.batch; h->S = (int)round_up(c.batch, SEG_ALIGN); h->tiles_m = ceil_div(c.batch, 128);
+    h->Bg = c.batch * c.world;
+    h->Dp = pad64(c.d_in); h->nzp = pad64(c.noise_size);
+    h->F = c.d_hidden[4]; h->Fp = pad64(h->F);
+    const int B = h->B, S = h->S, tm = h->tiles_m;
+    Arena a; a.base = base;
+
+    h->state = a.take<DevState>(2);
+    h->step_out = a.take<float>(4);
+    h->accum = a.take<float>(4);
+    h->err_count = a.take<int>(4);
+
+    // ---- tensors -----------------------------------------------------------------------------
+    const int gdim[4] = {c.noise_size, c.g_hidden[0], c.g_hidden[1], c.d_in};
+    const int ddim[7] = {c.d_in, c.d_hidden[0], c.d_hidden[1], c.d_hidden[2], c.d_hidden[3], c.d_hidden[4], c.num_classes};
+    h->gt.assign(8, Tensor());
+    h->dt.assign(12, Tensor());
+    auto mk = [&](Tensor& t, int rows, int cols, int prow, int pcol, bool copies) {
+        t.rows = rows; t.cols = cols; t.prow = prow; t.pcol = pcol;
+        const size_t n = (size_t)prow * pcol;
+        t.p = a.take<float>(n); t.m = a.take<float>(n); t.v = a.take<float>(n);
+        t.w16 = t.wt16 = nullptr;
+        if (copies && h->bf16) { t.w16 = a.take<__bf16>(n); t.wt16 = a.take<__bf16>(n); }
+        t.g = nullptr; t.nslab = 0; t.slab_stride = 0; t.flat = nullptr;
+    };
+    // generator: W1 b1 gamma beta W2 b2 W3 b3
+    const int gW[3] = {0, 4, 6}, gb[3] = {1, 5, 7};
+    for (int l = 0; l < 3; ++l) {
+        const int K = gdim[l], N = gdim[l + 1], Kp = pad64(K), Np = pad64(N);
+        mk(h->gt[gW[l]], K, N, Kp, Np, true);
+        mk(h->gt[gb[l]], 1, N, 1, Np, false);
+        h->g[l] = Dense{K, N, Kp, Np, l < 2 ? ACT_SOFTPLUS : ACT_LINEAR, &h->gt[gW[l]], &h->gt[gb[l]], nullptr, 1};
+    }
+    mk(h->gt[2], 1, gdim[1], 1, pad64(gdim[1]), false);
+    mk(h->gt[3], 1, gdim[1], 1, pad64(gdim[1]), false);
+    for (int l = 0; l < 6; ++l) {
+        const int K = ddim[l], N = ddim[l + 1], Kp = pad64(K), Np = (l == 5) ? KMAX : pad64(N);
+        mk(h->dt[2 * l], K, N, Kp, Np, l < 5);
+        mk(h->dt[2 * l + 1], 1, N, 1, Np, false);
+        h->d[l] = Dense{K, N, Kp, Np, l < 5 ? ACT_RELU : ACT_LINEAR, &h->dt[2 * l], &h->dt[2 * l + 1], nullptr, 1};
+    }
+    // flat gradient buffers (padded layout, Keras order) + 4 scalars
+    auto flat = [&](std::vector<Tensor>& ts, float*& buf, size_t& n) {
+        n = 0;
+        for (auto& t : ts) n += (size_t)t.prow * t.pcol;
+        buf = a.take<float>(n + 4);
+        size_t o = 0;
+        for (auto& t : ts) { t.flat = buf ? buf + o : nullptr; o += (size_t)t.prow * t.pcol; }
+    };
+    flat(h->gt, h->flat_g, h->flat_g_n);
+    flat(h->dt, h->flat_d, h->flat_d_n);
+    const int N1p = h->g[0].Np;
+    h->r_bn_stats = a.take<float>(2 * N1p);
+    h->r_fm = a.take<float>(2 * h->Fp);
+    h->r_bn_bwd = a.take<float>(2 * N1p);
+    h->bn_mu = a.take<float>(N1p);
+    h->bn_rstd = a.take<float>(N1p);
+
+    // ---- activations ---------------------------------------------------------------------------
+    const size_t es = h->es;
+    auto act = [&](size_t rows, size_t cols) { return (void*)a.take<char>(rows * cols * es); };
+    h->zbuf = act(S, h->nzp);
+    h->h1 = act(S, N1p); h->hbn = act(S, N1p); h->h2 = act(S, h->g[1].Np);
+    for (int l = 0; l < 5; ++l) {
+        h->xin[l] = act(3 * (size_t)S, h->d[l].Kp);
+        h->ldm[l] = h->d[l].Np / 32;
+        h->mask[l] = a.take<uint32_t>(3 * (size_t)S * h->ldm[l]);
+        h->dpre[l] = act(3 * (size_t)S, h->d[l].Np);
+    }
+    h->feat = act(3 * (size_t)S, h->Fp);
+    h->dxfake = act(S, h->Dp); h->dpre2g = act(S, h->g[1].Np); h->dhbn = act(S, N1p); h->dpre1g = act(S, N1p);
+    h->logits = a.take<float>(3 * (size_t)S * KMAX);
+
+    // ---- partial sums ----------------------------------------------------------------------------
+    h->cs_bn1 = a.take<float>((size_t)tm * N1p); h->cs_bn2 = a.take<float>((size_t)tm * N1p);
+    for (int l = 0; l < 4; ++l) h->cs_db[l] = a.take<float>(3 * (size_t)tm * h->d[l].Np);
+    h->cs_f = a.take<float>(2 * (size_t)tm * h->Fp);
+    h->cs_db3g = a.take<float>((size_t)tm * h->Dp);
+    h->cs_db2g = a.take<float>((size_t)tm * h->g[1].Np);
+    h->cs_dbeta = a.take<float>((size_t)tm * N1p); h->cs_dgamma = a.take<float>((size_t)tm * N1p);
+    h->bnb_rows_per_block = 32; h->bnb_blocks = ceil_div(B, 32);
+    h->db1g_part = a.take<float>((size_t)h->bnb_blocks * N1p);
+    h->nblk_head = 3 * ceil_div(B, HEAD_ROWS);
+    h->dw6_part = a.take<float>((size_t)h->nblk_head * h->Fp * KMAX);
+    h->db6_part = a.take<float>((size_t)h->nblk_head * KMAX);
+    h->dbf_part = a.take<float>((size_t)h->nblk_head * h->Fp);
+    h->loss_part = a.take<float>((size_t)h->nblk_head * 4);
+
+    // ---- weight-gradient slabs ---------------------------------------------------------------------
+    for (int l = 0; l < 5; ++l) {
+        Dense& L = h->d[l];
+        L.splits = choose_splits(L.Kp, L.Np, 3, B);
+        L.slabs = a.take<float>((size_t)3 * L.splits * L.Kp * L.Np);
+    }
+    for (int l = 0; l < 3; ++l) {
+        Dense& L = h->g[l];
+        L.splits = choose_splits(L.Kp, L.Np, 1, B);
+        L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
+    }
+    // ---- fused-mode gradient sources ----------------------------------------------------------------
+    auto src = [&](Tensor& t, const float* g, int nslab, long stride) { t.g = g; t.nslab = nslab; t.slab_stride = stride; };
+    for (int l = 0; l < 5; ++l) src(*h->d[l].W, h->d[l].slabs, 3 * h->d[l].splits, (long)h->d[l].Kp * h->d[l].Np);
+    for (int l = 0; l < 4; ++l) src(*h->d[l].b, h->cs_db[l], 3 * tm, h->d[l].Np);
+    src(*h->d[4].b, h->dbf_part, h->nblk_head, h->Fp);
+    src(*h->d[5].W, h->dw6_part, h->nblk_head, (long)h->Fp * KMAX);
+    src(*h->d[5].b, h->db6_part, h->nblk_head, KMAX);
+    for (int l = 0; l < 3; ++l) src(*h->g[l].W, h->g[l].slabs, h->g[l].splits, (long)h->g[l].Kp * h->g[l].Np);
+    src(*h->g[0].b, h->db1g_part, h->bnb_blocks, N1p);
+    src(h->gt[2], h->cs_dgamma, tm, N1p);
+    src(h->gt[3], h->cs_dbeta, tm, N1p);
+    src(*h->g[1].b, h->cs_db2g, tm, h->g[1].Np);
+    src(*h->g[2].b, h->cs_db3g, tm, h->Dp);
+
+    // ---- Adam tile tables ------------------------------------------------------------------------------
+    auto count_tiles = [&](std::vector<Tensor>& ts) {
+        int n = 0;
+        for (auto& t : ts) n += ceil_div(t.prow, 64) * ceil_div(t.pcol, 64);
+        return n;
+    };
+    h->ntiles_g = count_tiles(h->gt); h->ntiles_d = count_tiles(h->dt);
+    h->tiles_g_dev = a.take<AdamTile>(h->ntiles_g);
+    h->tiles_d_dev = a.take<AdamTile>(h->ntiles_d);
+
+    *bytes_out = (a.off + 255) & ~(size_t)255;
+    return 0;
+}
+
+int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n, hipStream_t s) {
+    std::vector<AdamTile> v;
+    for (auto& t : ts)
+        for (int r0 = 0; r0 < t.prow; r0 += 64)
+            for (int c0 = 0; c0 < t.pcol; c0 += 64) {
+                AdamTile a;
+                const long off = (long)r0 * t.pcol + c0;
+                a.p = t.p + off; a.m = t.m + off; a.v = t.v + off;
+                a.g = t.g + off; a.nslab = t.nslab; a.slab_stride = t.slab_stride;
+                a.flat = t.flat + off;
+                a.w16 = t.w16 ? t.w16 + off : nullptr;
+                a.wt16 = t.wt16 ? t.wt16 + (long)c0 * t.prow + r0 : nullptr;
+                a.ld = t.pcol; a.ldt = t.prow;
+                a.rows = std::min(64, t.prow - r0); a.cols = std::min(64, t.pcol - c0);
+                v.push_back(a);
+            }
+    if ((int)v.size() != n) return fail(-20, "tile count mismatch");
+    HIPCHK(hipMemcpyAsync(dev, v.data(), sizeof(AdamTile) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));      // v dies at scope exit
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM call sites
+// ------------------------------------------------------------------------------------------------
+int run_gemm(mrgan_handle* h, int epi, const GemmArgs& g, hipStream_t s) {
+    return h->bf16 ? launch_gemm_bf16(epi, g, s) : launch_gemm_f32(epi, g, s);
+}
+
+Epi base_epi(mrgan_handle* h) {
+    Epi e;
+    memset(&e, 0, sizeof e);
+    e.seed = h->cfg.seed;
+    e.row0 = (uint32_t)(h->cfg.rank * h->B);
+    e.st = h->state + h->cur;
+    return e;
+}
+
+// Y = act(X W + b): X [nb][S][Kp] -> out [nb][S][Np]
+int dense_fwd(mrgan_handle* h, const Dense& L, const void* x, int rows, int nb, void* out, int act, float sigma, uint32_t site,
+              uint32_t seg0, uint32_t* mask, int ldm, int cs_mode, float* cs1, float* cs2, bool noise_state, hipStream_t s) {
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.M = rows; g.N = L.Np; g.K = L.Kp; g.nbatch = nb; g.splits = 1; g.kchunk = L.Kp; g.tiles_m = ceil_div(rows, 128);
+    g.A = x; g.a_bs = (long)h->S * L.Kp; g.a_si = L.Kp; g.a_sk = 1;
+    if (h->bf16) { g.B = L.W->wt16; g.b_sj = L.Kp; g.b_sk = 1; }
+    else { g.B = L.W->p; g.b_sk = L.Np; g.b_sj = 1; }
+    g.e = base_epi(h);
+    if (!noise_state) g.e.st = nullptr;
+    g.e.act = act; g.e.n_valid = L.N; g.e.bias = L.b->p;
+    g.e.out = out; g.e.out_bs = (long)h->S * L.Np; g.e.ldo = L.Np;
+    g.e.sigma = sigma; g.e.site = site; g.e.seg0 = seg0;
+    g.e.mask = mask; g.e.mask_bs = (long)h->S * ldm; g.e.ldm = ldm;
+    g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Np;
+    return run_gemm(h, EPI_FWD, g, s);
+}
+
+// dX = (dY W^T) * act'(prev): dY [nb][S][Np] -> out [nb][S][Kp]
+int dense_dx(mrgan_handle* h, const Dense& L, const void* dy, int rows, int nb, void* out, int act, int n_valid,
+             const uint32_t* mask, int ldm, const void* hprev, int cs_mode, float* cs1, float* cs2, hipStream_t s) {
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.M = rows; g.N = L.Kp; g.K = L.Np; g.nbatch = nb; g.splits = 1; g.kchunk = L.Np; g.tiles_m = ceil_div(rows, 128);
+    g.A = dy; g.a_bs = (long)h->S * L.Np; g.a_si = L.Np; g.a_sk = 1;
+    g.B = h->bf16 ? (const void*)L.W->w16 : (const void*)L.W->p; g.b_sk = 1; g.b_sj = L.Np;
+    g.e = base_epi(h);
+    g.e.act = act; g.e.n_valid = n_valid;
+    g.e.out = out; g.e.out_bs = (long)h->S * L.Kp; g.e.ldo = L.Kp;
+    g.e.mask = (uint32_t*)mask; g.e.mask_bs = (long)h->S * ldm; g.e.ldm = ldm;
+    g.e.h = hprev; g.e.h_bs = (long)h->S * L.Kp; g.e.ldh = L.Kp;
+    g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Kp;
+    g.e.bn_mu = h->bn_mu; g.e.bn_rstd = h->bn_rstd;
+    return run_gemm(h, EPI_DX, g, s);
+}
+
+// dW slabs = X^T dY over `rows` rows of each of nb segments
+int dense_dw(mrgan_handle* h, const Dense& L, const void* x, const void* dy, int rows, int nb, hipStream_t s) {
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.M = L.Kp; g.N = L.Np; g.K = rows; g.nbatch = nb; g.splits = L.splits; g.tiles_m = ceil_div(L.Kp, 128);
+    g.kchunk = (int)round_up(ceil_div(rows, L.splits), 64);
+    g.A = x; g.a_bs = (long)h->S * L.Kp; g.a_si = 1; g.a_sk = L.Kp;
+    g.B = dy; g.b_bs = (long)h->S * L.Np; g.b_sk = L.Np; g.b_sj = 1;
+    g.e = base_epi(h);
+    g.e.ldo = L.Np; g.e.slab = L.slabs; g.e.slab_stride = (long)L.Kp * L.Np;
+    return run_gemm(h, EPI_SLAB, g, s);
+}
+
+void* rowptr(mrgan_handle* h, void* base, long row, int ld) { return (char*)base + (size_t)row * ld * h->es; }
+
+int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t s) {
+    AdamArgs a;
+    memset(&a, 0, sizeof a);
+    a.tiles = net == MRGAN_NET_D ? h->tiles_d_dev : h->tiles_g_dev;
+    a.ntiles = net == MRGAN_NET_D ? h->ntiles_d : h->ntiles_g;
+    a.mode = mode; a.b1 = h->cfg.beta1; a.b2 = h->cfg.beta2; a.eps = h->cfg.adam_eps;
+    a.st = h->state + h->cur;
+    if (with_metrics) {
+        a.loss_part = h->loss_part; a.nloss_part = h->nblk_head; a.inv_rows = 1.0f / (float)h->Bg;
+        a.step_out = h->step_out; a.accum = h->accum;
+        a.flat_tail = h->flat_d + h->flat_d_n;
+    }
+    return launch_adam(a, s);
+}
+
+// generator forward up to the BatchNorm statistics (phase *_GEN) and from there to the fake rows
+int gen_fwd_head(mrgan_handle* h, hipStream_t s) {
+    CHK(dense_fwd(h, h->g[0], h->zbuf, h->B, 1, h->h1, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_SUM_SQ, h->cs_bn1, h->cs_bn2,
+                  true, s));
+    if (h->sync_stats) {
+        const int n = h->g[0].Np;
+        CHK(launch_colsum_finalize(h->cs_bn1, h->tiles_m, n, n, h->r_bn_stats, s));
+        CHK(launch_colsum_finalize(h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats + n, s));
+    }
+    return 0;
+}
+int gen_fwd_tail(mrgan_handle* h, int fake_seg_slot, uint32_t fake_seg_id, hipStream_t s) {
+    const int n = h->g[0].Np;
+    BnApplyArgs b;
+    memset(&b, 0, sizeof b);
+    b.h = h->h1; b.out = h->hbn; b.ld = n; b.rows = h->B; b.cols = h->g[0].N;
+    if (h->sync_stats) { b.cs1 = h->r_bn_stats; b.cs2 = h->r_bn_stats + n; b.npart = 1; }
+    else { b.cs1 = h->cs_bn1; b.cs2 = h->cs_bn2; b.npart = h->tiles_m; }
+    b.ldcs = n; b.count = (float)h->Bg; b.eps = h->cfg.bn_eps;
+    b.gamma = h->gt[2].p; b.beta = h->gt[3].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
+    CHK(launch_bn_apply(h->bf16, b, s));
+    CHK(dense_fwd(h, h->g[1], h->hbn, h->B, 1, h->h2, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_NONE, nullptr, nullptr, true, s));
+    // generator output + GaussianNoise(sigma0) = the discriminator's noisy input rows of the fake segment
+    void* out = rowptr(h, h->xin[0], (long)fake_seg_slot * h->S, h->Dp);
+    CHK(dense_fwd(h, h->g[2], h->h2, h->B, 1, out, ACT_LINEAR, h->cfg.sigma[0], 0, fake_seg_id, nullptr, 0, CS_NONE, nullptr,
+                  nullptr, true, s));
+    return 0;
+}
+
+// discriminator dense 1..5 over nb segments (learning phase 1: noise on)
+int disc_fwd_train(mrgan_handle* h, int nb, bool fm_sums, hipStream_t s) {
+    for (int l = 0; l < 5; ++l) {
+        void* out = l < 4 ? h->xin[l + 1] : h->feat;
+        const float sigma = l < 4 ? h->cfg.sigma[l + 1] : 0.f;
+        const bool last = l == 4;
+        CHK(dense_fwd(h, h->d[l], h->xin[l], h->B, nb, out, ACT_RELU, sigma, (uint32_t)(l + 1), 0, h->mask[l], h->ldm[l],
+                      (last && fm_sums) ? CS_SUM : CS_NONE, h->cs_f, nullptr, true, s));
+    }
+    return 0;
+}
+
+int stage_common(StageArgs& st, mrgan_handle* h, const float* z, int stream_mode, int advance_batch, int slot) {
+    StageSeg& zs = st.s[slot];
+    memset(&zs, 0, sizeof zs);
+    zs.src = z; zs.ld = h->cfg.noise_size; zs.rows = h->B; zs.cols = h->cfg.noise_size; zs.cols_pad = h->nzp;
+    zs.out = h->zbuf; zs.ldo = h->nzp; zs.sigma = 0.f; zs.site = SITE_Z; zs.seg = 0; zs.gen = z ? 0 : 1; zs.stream = z ? stream_mode : 0;
+    st.nseg = slot + 1;
+    st.seed = h->cfg.seed; st.row0 = (uint32_t)(h->cfg.rank * h->B);
+    st.cur = h->state + h->cur; st.next = h->state + (h->cur ^ 1); st.advance_batch = advance_batch;
+    st.lr = h->cfg.lr; st.b1 = h->cfg.beta1; st.b2 = h->cfg.beta2;
+    return 0;
+}
+void data_seg(StageSeg& sg, mrgan_handle* h, const float* x, const int32_t* idx, long ld, int slot, uint32_t seg_id, int stream_mode) {
+    memset(&sg, 0, sizeof sg);
+    sg.src = x; sg.idx = idx; sg.ld = ld; sg.rows = h->B; sg.cols = h->cfg.d_in; sg.cols_pad = h->Dp;
+    sg.out = rowptr(h, h->xin[0], (long)slot * h->S, h->Dp); sg.ldo = h->Dp;
+    sg.sigma = h->cfg.sigma[0]; sg.site = 0; sg.seg = seg_id; sg.gen = 0; sg.stream = stream_mode;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// discriminator sub-step
+// ---------------------------------------------------------------------------------------------------
+int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t s) {
+    const int B = h->B;
+    if (phase == MRGAN_D_GEN) {
+        StageArgs st;
+        memset(&st, 0, sizeof st);
+        data_seg(st.s[0], h, a->x_lab_dev, a->idx_lab_dev, a->ld_x_lab, 0, 0, a->stream_mode);
+        data_seg(st.s[1], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);
+        stage_common(st, h, a->z_dev, a->stream_mode, 0, 2);
+        CHK(launch_stage(h->bf16, st, s));
+        CHK(gen_fwd_head(h, s));
+    } else if (phase == MRGAN_D_MAIN) {
+        CHK(gen_fwd_tail(h, 2, 2, s));
+        CHK(disc_fwd_train(h, 3, false, s));
+        HeadArgs hd;
+        memset(&hd, 0, sizeof hd);
+        hd.f = h->feat; hd.f_bs = (long)h->S * h->Fp; hd.ldf = h->Fp; hd.rows = B; hd.nseg = 3;
+        hd.seg_kind[0] = HEAD_LAB; hd.seg_kind[1] = HEAD_UNL; hd.seg_kind[2] = HEAD_FAKE;
+        hd.feat = h->Fp; hd.feat_valid = h->F; hd.classes = h->cfg.num_classes;
+        hd.w = h->dt[10].p; hd.ldw = KMAX; hd.b = h->dt[11].p;
+        hd.labels = a->labels_dev; hd.st = h->state + h->cur; hd.labels_stream = a->stream_mode;
+        hd.inv_count = 1.0f / (float)h->Bg; hd.unl_weight = h->cfg.unlabeled_weight;
+        hd.logits = h->logits; hd.logits_bs = (long)h->S * KMAX;
+        hd.dpre = h->dpre[4]; hd.dpre_bs = (long)h->S * h->Fp; hd.ldd = h->Fp;
+        hd.dw_part = h->dw6_part; hd.db_part = h->db6_part; hd.dbf_part = h->dbf_part; hd.ldbf = h->Fp;
+        hd.loss_part = h->loss_part;
+        CHK(launch_head(h->bf16, hd, s));
+        for (int l = 4; l >= 1; --l)
+            CHK(dense_dx(h, h->d[l], h->dpre[l], B, 3, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
+                         nullptr, CS_SUM, h->cs_db[l - 1], nullptr, s));
+        for (int l = 0; l < 5; ++l) CHK(dense_dw(h, h->d[l], h->xin[l], h->dpre[l], B, 3, s));
+        if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_D, ADAM_REDUCE_ONLY, true, s));
+    } else if (phase == MRGAN_D_ADAM) {
+        CHK(run_adam(h, MRGAN_NET_D, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, true, s));
+        h->cur ^= 1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generator sub-step
+// ---------------------------------------------------------------------------------------------------
+int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s) {
+    const int B = h->B, tm = h->tiles_m, N1p = h->g[0].Np;
+    if (phase == MRGAN_G_GEN) {
+        StageArgs st;
+        memset(&st, 0, sizeof st);
+        data_seg(st.s[0], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);   // real rows -> slot 1
+        stage_common(st, h, a->z_dev, a->stream_mode, a->stream_mode ? 1 : 0, 1);
+        CHK(launch_stage(h->bf16, st, s));
+        CHK(gen_fwd_head(h, s));
+    } else if (phase == MRGAN_G_FEAT) {
+        CHK(gen_fwd_tail(h, 0, 0, s));                                                          // fake rows -> slot 0
+        CHK(disc_fwd_train(h, 2, true, s));
+        if (h->sync_stats) {
+            CHK(launch_colsum_finalize(h->cs_f, tm, h->Fp, h->Fp, h->r_fm, s));
+            CHK(launch_colsum_finalize(h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm + h->Fp, s));
+        }
+    } else if (phase == MRGAN_G_BWD) {
+        FmArgs f;
+        memset(&f, 0, sizeof f);
+        if (h->sync_stats) { f.cs = h->r_fm; f.npart_fake = 1; f.npart_real = 1; }
+        else { f.cs = h->cs_f; f.npart_fake = tm; f.npart_real = tm; }
+        f.ldcs = h->Fp; f.count = (float)h->Bg; f.feat = h->Fp; f.feat_valid = h->F;
+        f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B; f.rows_per_block = 32;
+        f.loss_out = h->step_out + 3; f.accum = h->accum + 3;
+        CHK(launch_fm(h->bf16, f, s));
+        for (int l = 4; l >= 1; --l)
+            CHK(dense_dx(h, h->d[l], h->dpre[l], B, 1, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
+                         nullptr, CS_NONE, nullptr, nullptr, s));
+        // d loss / d(generator output): noise is additive, so this is also d/d(fake x)
+        CHK(dense_dx(h, h->d[0], h->dpre[0], B, 1, h->dxfake, ACT_LINEAR, h->cfg.d_in, nullptr, 0, nullptr, CS_SUM, h->cs_db3g,
+                     nullptr, s));
+        CHK(dense_dx(h, h->g[2], h->dxfake, B, 1, h->dpre2g, ACT_SOFTPLUS, h->g[1].N, nullptr, 0, h->h2, CS_SUM, h->cs_db2g,
+                     nullptr, s));
+        CHK(dense_dx(h, h->g[1], h->dpre2g, B, 1, h->dhbn, ACT_LINEAR, h->g[0].N, nullptr, 0, h->h1, CS_SUM_XHAT, h->cs_dbeta,
+                     h->cs_dgamma, s));
+        if (h->sync_stats) {
+            CHK(launch_colsum_finalize(h->cs_dbeta, tm, N1p, N1p, h->r_bn_bwd, s));
+            CHK(launch_colsum_finalize(h->cs_dgamma, tm, N1p, N1p, h->r_bn_bwd + N1p, s));
+        }
+    } else if (phase == MRGAN_G_TAIL) {
+        BnBwdArgs b;
+        memset(&b, 0, sizeof b);
+        b.dy = h->dhbn; b.h = h->h1; b.dpre = h->dpre1g; b.ld = N1p; b.rows = B; b.cols = h->g[0].N;
+        if (h->sync_stats) { b.cs1 = h->r_bn_bwd; b.cs2 = h->r_bn_bwd + N1p; b.npart = 1; }
+        else { b.cs1 = h->cs_dbeta; b.cs2 = h->cs_dgamma; b.npart = tm; }
+        b.ldcs = N1p; b.count = (float)h->Bg; b.gamma = h->gt[2].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
+        b.db_part = h->db1g_part; b.rows_per_block = h->bnb_rows_per_block;
+        CHK(launch_bn_bwd(h->bf16, b, s));
+        CHK(dense_dw(h, h->g[2], h->h2, h->dxfake, B, 1, s));
+        CHK(dense_dw(h, h->g[1], h->hbn, h->dpre2g, B, 1, s));
+        CHK(dense_dw(h, h->g[0], h->zbuf, h->dpre1g, B, 1, s));
+        if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_G, ADAM_REDUCE_ONLY, false, s));
+    } else if (phase == MRGAN_G_ADAM) {
+        CHK(run_adam(h, MRGAN_NET_G, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, false, s));
+        h->cur ^= 1;
+    }
+    return 0;
+}
+
+int check_disc_args(const mrgan_handle* h, const mrgan_disc_args* a) {
+    if (!a || !a->x_lab_dev || !a->x_unl_dev || !a->labels_dev) return fail(-2, "disc_step: x_lab, x_unl and labels are required");
+    if (a->ld_x_lab < h->cfg.d_in || a->ld_x_unl < h->cfg.d_in) return fail(-2, "disc_step: row pitch smaller than d_in");
+    return 0;
+}
+int check_gen_args(const mrgan_handle* h, const mrgan_gen_args* a) {
+    if (!a || !a->x_unl_dev) return fail(-2, "gen_step: x_unl is required");
+    if (a->ld_x_unl < h->cfg.d_in) return fail(-2, "gen_step: row pitch smaller than d_in");
+    return 0;
+}
+
+// forward-only discriminator over n rows (learning phase 0), chunked through the training activations
+int eval_rows(mrgan_handle* h, const float* x, const int32_t* idx, long ld, const int32_t* labels, long n, float* logits_out,
+              hipStream_t s) {
+    const long cap = 3L * h->S;
+    for (long r0 = 0; r0 < n; r0 += cap) {
+        const int rows = (int)std::min(cap, n - r0);
+        StageArgs st;
+        memset(&st, 0, sizeof st);
+        StageSeg& sg = st.s[0];
+        sg.src = idx ? x : x + r0 * ld; sg.idx = idx ? idx + r0 : nullptr; sg.ld = ld; sg.rows = rows;
+        sg.cols = h->cfg.d_in; sg.cols_pad = h->Dp; sg.out = h->xin[0]; sg.ldo = h->Dp;
+        st.nseg = 1; st.seed = h->cfg.seed; st.cur = h->state + h->cur; st.next = nullptr;
+        CHK(launch_stage(h->bf16, st, s));
+        for (int l = 0; l < 5; ++l) {
+            // one "segment" of `rows` contiguous rows: batch stride is irrelevant with nb = 1
+            CHK(dense_fwd(h, h->d[l], h->xin[l], rows, 1, l < 4 ? h->xin[l + 1] : h->feat, ACT_RELU, 0.f, 0, 0, nullptr, 0, CS_NONE,
+                          nullptr, nullptr, false, s));
+        }
+        HeadArgs hd;
+        memset(&hd, 0, sizeof hd);
+        hd.f = h->feat; hd.ldf = h->Fp; hd.rows = rows; hd.nseg = 1; hd.seg_kind[0] = HEAD_EVAL;
+        hd.feat = h->Fp; hd.feat_valid = h->F; hd.classes = h->cfg.num_classes;
+        hd.w = h->dt[10].p; hd.ldw = KMAX; hd.b = h->dt[11].p;
+        hd.labels = labels ? labels + r0 : nullptr;
+        if (!labels) hd.seg_kind[0] = HEAD_LOGITS;
+        hd.st = h->state + h->cur; hd.labels_stream = 0;
+        hd.logits = h->logits; hd.err_count = labels ? h->err_count : nullptr;
+        CHK(launch_head(h->bf16, hd, s));
+        if (logits_out)
+            HIPCHK(hipMemcpy2DAsync(logits_out + r0 * h->cfg.num_classes, sizeof(float) * h->cfg.num_classes, h->logits,
+                                    sizeof(float) * KMAX, sizeof(float) * h->cfg.num_classes, rows, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+Tensor* find_tensor(mrgan_handle* h, int net, int idx) {
+    std::vector<Tensor>& ts = net == MRGAN_NET_G ? h->gt : h->dt;
+    if (net != MRGAN_NET_G && net != MRGAN_NET_D) return nullptr;
+    if (idx < 0 || idx >= (int)ts.size()) return nullptr;
+    return &ts[idx];
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* mrgan_last_error(void) { return g_err.c_str(); }
+
+int mrgan_default_config(mrgan_config* c, int32_t d_in, int32_t batch) {
+    if (!c) return fail(-1, "null config");
+    memset(c, 0, sizeof *c);
+    c->d_in = d_in; c->batch = batch; c->noise_size = 100;
+    c->g_hidden[0] = 500; c->g_hidden[1] = 500;
+    const int dh[5] = {1000, 500, 250, 250, 250};
+    const float sg[5] = {0.3f, 0.5f, 0.5f, 0.5f, 0.5f};
+    for (int i = 0; i < 5; ++i) { c->d_hidden[i] = dh[i]; c->sigma[i] = sg[i]; }
+    c->num_classes = 6; c->dtype = MRGAN_F32;
+    c->lr = 0.0006f; c->beta1 = 0.5f; c->beta2 = 0.999f; c->adam_eps = 1e-8f; c->bn_eps = 2e-5f;
+    c->unlabeled_weight = 1.0f; c->seed = 0x5EED5EEDULL; c->rank = 0; c->world = 1; c->flags = 0;
+    return 0;
+}
+
+int mrgan_workspace_bytes(const mrgan_config* cfg, size_t* bytes) {
+    if (!cfg || !bytes) return fail(-1, "null argument");
+    int r = validate(*cfg);
+    if (r) return r;
+    mrgan_handle tmp;
+    tmp.cfg = *cfg;
+    return layout(&tmp, nullptr, bytes);
+}
+
+int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_stream stream, mrgan_handle** out) {
+    if (!cfg || !out) return fail(-1, "null argument");
+    int r = validate(*cfg);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    mrgan_handle* h = new mrgan_handle();
+    h->cfg = *cfg;
+    size_t need = 0;
+    layout(h, nullptr, &need);
+    h->own_ws = workspace == nullptr;
+    if (workspace) {
+        if (bytes < need) { delete h; return fail(-3, "workspace too small: %zu < %zu", bytes, need); }
+        if (((uintptr_t)workspace & 255) != 0) { delete h; return fail(-3, "workspace must be 256-byte aligned"); }
+        h->ws = (char*)workspace;
+    } else {
+        hipError_t e = hipMalloc((void**)&h->ws, need);
+        if (e != hipSuccess) { delete h; return fail(-10, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); }
+    }
+    h->ws_bytes = need;
+    layout(h, h->ws, &need);
+    h->cur = 0; h->graph_ready = false; h->graph_exec = nullptr;
+    if (init_kernel_attributes() != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "hipFuncSetAttribute failed"); }
+#define CREATE_CHK(x)                                           \
+    do {                                                        \
+        if ((x) != hipSuccess) {                                \
+            fail(-10, "%s failed during create", #x);           \
+            if (h->own_ws) hipFree(h->ws);                      \
+            delete h;                                           \
+            return -10;                                         \
+        }                                                       \
+    } while (0)
+    // zero everything: padding of weights/activations must be exactly zero and stays so
+    CREATE_CHK(hipMemsetAsync(h->ws, 0, h->ws_bytes, s));
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, s, h->state, 0u, 0u, cfg->lr, cfg->beta1, cfg->beta2);
+    r = upload_tiles(h, h->gt, h->tiles_g_dev, h->ntiles_g, s);
+    if (!r) r = upload_tiles(h, h->dt, h->tiles_d_dev, h->ntiles_d, s);
+    if (r) { if (h->own_ws) hipFree(h->ws); delete h; return r; }
+    // BN gamma defaults to one (Keras); dense weights stay zero until mrgan_set_weights
+    std::vector<float> ones(h->gt[2].cols, 1.0f);
+    CREATE_CHK(hipMemcpyAsync(h->gt[2].p, ones.data(), sizeof(float) * ones.size(), hipMemcpyHostToDevice, s));
+    CREATE_CHK(hipStreamSynchronize(s));
+    *out = h;
+    return 0;
+}
+
+int mrgan_destroy(mrgan_handle* h) {
+    if (!h) return 0;
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->own_ws && h->ws) hipFree(h->ws);
+    delete h;
+    return 0;
+}
+
+int mrgan_num_tensors(const mrgan_handle* h, int net, int* n) {
+    if (!h || !n) return fail(-1, "null argument");
+    *n = net == MRGAN_NET_G ? 8 : 12;
+    return 0;
+}
+
+int mrgan_tensor_shape(const mrgan_handle* h, int net, int idx, int* rows, int* cols) {
+    Tensor* t = find_tensor((mrgan_handle*)h, net, idx);
+    if (!t) return fail(-1, "no such tensor (%d,%d)", net, idx);
+    *rows = t->rows; *cols = t->cols;
+    return 0;
+}
+
+int mrgan_set_weights(mrgan_handle* h, int net, int idx, const float* src, mrgan_stream stream) {
+    Tensor* t = find_tensor(h, net, idx);
+    if (!t || !src) return fail(-1, "set_weights: bad tensor or null source");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpy2DAsync(t->p, sizeof(float) * t->pcol, src, sizeof(float) * t->cols, sizeof(float) * t->cols, t->rows,
+                            hipMemcpyDeviceToDevice, s));
+    if (t->w16) hipLaunchKernelGGL(refresh_bf16_kernel, grid2d(t->prow, t->pcol), dim3(256), 0, s, t->p, t->w16, t->wt16, t->prow, t->pcol);
+    return 0;
+}
+
+int mrgan_get_weights(mrgan_handle* h, int net, int idx, float* dst, mrgan_stream stream) {
+    Tensor* t = find_tensor(h, net, idx);
+    if (!t || !dst) return fail(-1, "get_weights: bad tensor or null destination");
+    HIPCHK(hipMemcpy2DAsync(dst, sizeof(float) * t->cols, t->p, sizeof(float) * t->pcol, sizeof(float) * t->cols, t->rows,
+                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int mrgan_get_slot(mrgan_handle* h, int net, int idx, int which, float* dst, mrgan_stream stream) {
+    Tensor* t = find_tensor(h, net, idx);
+    if (!t || !dst || which < 0 || which > 2) return fail(-1, "get_slot: bad argument");
+    const float* src = which == 0 ? t->m : which == 1 ? t->v : t->flat;
+    HIPCHK(hipMemcpy2DAsync(dst, sizeof(float) * t->cols, src, sizeof(float) * t->pcol, sizeof(float) * t->cols, t->rows,
+                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int mrgan_set_slot(mrgan_handle* h, int net, int idx, int which, const float* src, mrgan_stream stream) {
+    Tensor* t = find_tensor(h, net, idx);
+    if (!t || !src || which < 0 || which > 1) return fail(-1, "set_slot: bad argument");
+    float* dst = which == 0 ? t->m : t->v;
+    HIPCHK(hipMemcpy2DAsync(dst, sizeof(float) * t->pcol, src, sizeof(float) * t->cols, sizeof(float) * t->cols, t->rows,
+                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int mrgan_get_iterations(mrgan_handle* h, mrgan_stream stream, uint32_t* it) {
+    if (!h || !it) return fail(-1, "null argument");
+    DevState st;
+    HIPCHK(hipMemcpyAsync(&st, h->state + h->cur, sizeof st, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    *it = st.iter;
+    return 0;
+}
+
+int mrgan_set_iterations(mrgan_handle* h, uint32_t iterations, uint32_t batch_counter, mrgan_stream stream) {
+    if (!h) return fail(-1, "null handle");
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->state, iterations, batch_counter,
+                       h->cfg.lr, h->cfg.beta1, h->cfg.beta2);
+    return 0;
+}
+
+int mrgan_disc_step(mrgan_handle* h, const mrgan_disc_args* a, int p0, int p1, float* out3, mrgan_stream stream) {
+    if (!h) return fail(-1, "null handle");
+    int r = check_disc_args(h, a);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    if (p1 < 0) p1 = MRGAN_D_NPHASES - 1;
+    for (int p = p0; p <= p1; ++p) { r = disc_phase(h, a, p, s); if (r) return r; }
+    if (out3) {
+        HIPCHK(hipMemcpyAsync(out3, h->step_out, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int p0, int p1, float* out1, mrgan_stream stream) {
+    if (!h) return fail(-1, "null handle");
+    int r = check_gen_args(h, a);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    if (p1 < 0) p1 = MRGAN_G_NPHASES - 1;
+    for (int p = p0; p <= p1; ++p) { r = gen_phase(h, a, p, s); if (r) return r; }
+    if (out1) {
+        HIPCHK(hipMemcpyAsync(out1, h->step_out + 3, sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_args* g, mrgan_stream stream) {
+    if (!h) return fail(-1, "null handle");
+    int r = check_disc_args(h, d);
+    if (!r) r = check_gen_args(h, g);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const bool want_graph = (h->cfg.flags & MRGAN_FLAG_GRAPH) && d->stream_mode && g->stream_mode && !h->flat_grads && !h->sync_stats;
+    if (!want_graph) {
+        r = mrgan_disc_step(h, d, 0, -1, nullptr, stream);
+        if (!r) r = mrgan_gen_step(h, g, 0, -1, nullptr, stream);
+        return r;
+    }
+    // A pair flips the state slot twice, so every kernel argument is identical on every replay as long as
+    // the slot parity and the caller's pointers are those of the capture.
+    if (h->graph_ready && (h->graph_cur != h->cur || memcmp(&h->graph_d, d, sizeof *d) != 0 || memcmp(&h->graph_g, g, sizeof *g) != 0)) {
+        hipGraphExecDestroy(h->graph_exec);
+        h->graph_exec = nullptr; h->graph_ready = false;
+    }
+    if (!h->graph_ready) {
+        hipGraph_t graph;
+        const int cur0 = h->cur;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        r = mrgan_disc_step(h, d, 0, -1, nullptr, stream);
+        if (!r) r = mrgan_gen_step(h, g, 0, -1, nullptr, stream);
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (r) return r;
+        if (e != hipSuccess) return fail(-10, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail(-10, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        h->graph_d = *d; h->graph_g = *g; h->graph_cur = cur0; h->graph_ready = true;
+    }
+    HIPCHK(hipGraphLaunch(h->graph_exec, s));
+    return 0;
+}
+
+int mrgan_region(mrgan_handle* h, int region, void** ptr, size_t* bytes) {
+    if (!h || !ptr || !bytes) return fail(-1, "null argument");
+    const size_t n1 = (size_t)h->g[0].Np;
+    switch (region) {
+        case MRGAN_REGION_BN_STATS: *ptr = h->r_bn_stats; *bytes = 2 * n1 * 4; break;
+        case MRGAN_REGION_FM_MOMENTS: *ptr = h->r_fm; *bytes = 2 * (size_t)h->Fp * 4; break;
+        case MRGAN_REGION_BN_BWD: *ptr = h->r_bn_bwd; *bytes = 2 * n1 * 4; break;
+        case MRGAN_REGION_GRAD_D: *ptr = h->flat_d; *bytes = (h->flat_d_n + 4) * 4; break;
+        case MRGAN_REGION_GRAD_G: *ptr = h->flat_g; *bytes = (h->flat_g_n + 4) * 4; break;
+        case MRGAN_REGION_WORKSPACE: *ptr = h->ws; *bytes = h->ws_bytes; break;
+        default: return fail(-1, "unknown region %d", region);
+    }
+    return 0;
+}
+
+int mrgan_eval_error(mrgan_handle* h, const float* x, const int32_t* idx, int64_t ld, const int32_t* labels, int64_t n,
+                     float* err_host, mrgan_stream stream) {
+    if (!h || !x || !labels || !err_host || n < 1) return fail(-1, "eval_error: bad argument");
+    if (ld < h->cfg.d_in) return fail(-2, "eval_error: row pitch smaller than d_in");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(h->err_count, 0, sizeof(int), s));
+    int r = eval_rows(h, x, idx, ld, labels, n, nullptr, s);
+    if (r) return r;
+    int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, h->err_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *err_host = (float)((double)cnt / (double)n);
+    return 0;
+}
+
+int mrgan_predict_logits(mrgan_handle* h, const float* x, const int32_t* idx, int64_t ld, int64_t n, float* logits,
+                         mrgan_stream stream) {
+    if (!h || !x || !logits || n < 1) return fail(-1, "predict_logits: bad argument");
+    if (ld < h->cfg.d_in) return fail(-2, "predict_logits: row pitch smaller than d_in");
+    return eval_rows(h, x, idx, ld, nullptr, n, logits, (hipStream_t)stream);
+}
+
+int mrgan_read_metrics(mrgan_handle* h, float* out8, int reset, mrgan_stream stream) {
+    if (!h || !out8) return fail(-1, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(out8, h->accum, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out8 + 4, h->step_out, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (reset) HIPCHK(hipMemsetAsync(h->accum, 0, 4 * sizeof(float), s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols, float* out,
+                      mrgan_stream stream) {
+    if (!h || !out) return fail(-1, "null argument");
+    CHK(launch_noise_debug(h->cfg.seed, site, seg, step, row0, rows, cols, out, (hipStream_t)stream));
+    return 0;
+}
+
+int mrgan_debug_tr_probe(uint16_t* out, mrgan_stream stream) {
+    if (!out) return fail(-1, "null argument");
+    CHK(launch_tr_probe(out, (hipStream_t)stream));
+    return 0;
+}
+
+int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a, const float* b, const float* bias, int act,
+                     int splits, float* out, mrgan_stream stream) {
+    // op 0: out[m,n] = act(a[m,k] b[k,n] + bias) ; op 1: out[m,k] = a[m,n] b[k,n]^T ; op 2: out[k,n] = a[m,k]^T b[m,n]
+    if ((n % 64) || (k % 64)) return fail(-1, "debug_gemm: n and k must be multiples of 64");
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf = dtype == MRGAN_BF16;
+    const size_t es = bf ? 2 : 4;
+    const int a_cols = op == 1 ? n : k, b_rows = op == 2 ? m : k;
+    const int o_rows = op == 2 ? k : m, o_cols = op == 1 ? k : n;
+    void *ta = nullptr, *tb = nullptr, *to = nullptr;
+    float* slabs = nullptr;
+    DevState* st = nullptr;
+    HIPCHK(hipMalloc(&ta, (size_t)m * a_cols * es));
+    HIPCHK(hipMalloc(&tb, (size_t)b_rows * n * es));
+    HIPCHK(hipMalloc(&to, (size_t)o_rows * o_cols * es));
+    HIPCHK(hipMalloc((void**)&st, sizeof(DevState) * 2));
+    HIPCHK(hipMemsetAsync(st, 0, sizeof(DevState) * 2, s));
+    const bool tr_b = bf && op == 0;       // the bf16 forward reads the transposed weight copy
+    if (bf) {
+        hipLaunchKernelGGL(convert_kernel<__bf16>, grid2d(m, a_cols), dim3(256), 0, s, a, (long)a_cols, (__bf16*)ta, (long)a_cols, m, a_cols, m, a_cols, 0);
+        hipLaunchKernelGGL(convert_kernel<__bf16>, grid2d(b_rows, n), dim3(256), 0, s, b, (long)n, (__bf16*)tb, (long)(tr_b ? b_rows : n), b_rows, n, b_rows, n, tr_b ? 1 : 0);
+    } else {
+        HIPCHK(hipMemcpyAsync(ta, a, (size_t)m * a_cols * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(tb, b, (size_t)b_rows * n * 4, hipMemcpyDeviceToDevice, s));
+    }
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.nbatch = 1; g.splits = 1; g.A = ta; g.B = tb;
+    g.e.st = st; g.e.out = to;
+    int epi;
+    if (op == 0) {
+        epi = EPI_FWD; g.M = m; g.N = n; g.K = k; g.kchunk = k; g.a_si = k; g.a_sk = 1;
+        if (bf) { g.b_sj = k; g.b_sk = 1; } else { g.b_sk = n; g.b_sj = 1; }
+        g.e.act = act; g.e.n_valid = n; g.e.bias = bias; g.e.ldo = n;
+    } else if (op == 1) {
+        epi = EPI_DX; g.M = m; g.N = k; g.K = n; g.kchunk = n; g.a_si = n; g.a_sk = 1; g.b_sk = 1; g.b_sj = n;
+        g.e.act = ACT_LINEAR; g.e.n_valid = k; g.e.ldo = k;
+    } else {
+        epi = EPI_SLAB; g.M = k; g.N = n; g.K = m; g.splits = std::max(1, splits);
+        g.kchunk = (int)round_up(ceil_div(m, g.splits), 64);
+        g.a_si = 1; g.a_sk = k; g.b_sk = n; g.b_sj = 1;
+        HIPCHK(hipMalloc((void**)&slabs, (size_t)g.splits * k * n * 4));
+        g.e.slab = slabs; g.e.slab_stride = (long)k * n; g.e.ldo = n;
+    }
+    g.tiles_m = ceil_div(g.M, 128);
+    int r = bf ? launch_gemm_bf16(epi, g, s) : launch_gemm_f32(epi, g, s);
+    if (!r) {
+        if (op == 2) hipLaunchKernelGGL(sum_slabs_kernel, dim3(ceil_div((long)k * n, 256)), dim3(256), 0, s, slabs, g.splits, (long)k * n, (long)k * n, out);
+        else if (bf) hipLaunchKernelGGL(to_f32_kernel<__bf16>, grid2d(o_rows, o_cols), dim3(256), 0, s, (const __bf16*)to, (long)o_cols, out, (long)o_cols, o_rows, o_cols);
+        else hipMemcpyAsync(out, to, (size_t)o_rows * o_cols * 4, hipMemcpyDeviceToDevice, s);
+    }
+    hipStreamSynchronize(s);
+    hipFree(ta); hipFree(tb); hipFree(to); hipFree(st);
+    if (slabs) hipFree(slabs);
+    if (r) return fail(r, "debug_gemm: launch failed (%d)", r);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+"""Drop-in entry points of the reference script: mr_gan(), dataset() and the --tables harness.
+
+    mr_gan(X, y, percentlabeled=50, percentunlabeled=None, epochs=100, trainTestSets=None, verbose=False) -> test error
+        same signature and return value as mr_gan.py:73 / :234
+    dataset(modalities=0, forcetempTime=4, contactmicTime=0.2, leaveObjectOut=False, verbose=False)
+        same signature as mr_gan.py:23
+    python -m mr_gan_amd.mr_gan --tables 1 3 5 6 [-v]        (mr_gan.py:236-341)
+
+Extra keyword arguments (batch_size, dtype, seed, device) default to the reference's literals.
+"""
+import argparse
+import itertools
+import os
+import pickle
+import sys
+
+import numpy as np
+
+from mr_gan_amd.data import MATERIALS, select_labeled, standard_scale
+
+MODALITIES = ['Force', 'Temperature', 'Force and Temperature', 'Contact mic', 'Temperature and Contact Mic',
+              'Force, Temperature, and Contact Mic', 'Force and Contact Mic']          # mr_gan.py:237
+
+
+def mr_gan(X, y, percentlabeled=50, percentunlabeled=None, epochs=100, trainTestSets=None, verbose=False,
+           batch_size=50, dtype='float32', seed=None, device='cuda:0'):
+    from sklearn.model_selection import train_test_split
+    from sklearn.utils import shuffle
+
+    from mr_gan_amd.model import MRGAN
+
+    rs = np.random.RandomState(seed if seed is not None else np.random.randint(1 << 31))   # mr_gan.py:75 (unseeded there)
+    test_ratio = 200 * len(MATERIALS)                              # mr_gan.py:81
+    num_labeled_examples = int(10 * percentlabeled)                # mr_gan.py:82
+    num_unlabeled_examples = int(10 * percentunlabeled) if percentunlabeled is not None else None
+
+    if trainTestSets is None:                                      # mr_gan.py:87-90
+        X_train, X_test, y_train, y_test = train_test_split(X, y, test_size=test_ratio, stratify=y, random_state=rs)
+    else:
+        X_train, X_test, y_train, y_test = trainTestSets
+    if verbose:
+        print('Num of class examples in test set:', [int(np.sum(y_test == i)) for i in range(len(MATERIALS))])
+        print('X_train:', np.shape(X_train), 'y_train:', np.shape(y_train), 'X_test:', np.shape(X_test), 'y_test:',
+              np.shape(y_test))
+
+    X_train, X_test = standard_scale(X_train, X_test)              # mr_gan.py:96-98
+    X_train, y_train = shuffle(X_train, y_train, random_state=rs)  # mr_gan.py:101
+    x_labeled, y_labeled, x_unlabeled = select_labeled(X_train, y_train, num_labeled_examples, num_unlabeled_examples)
+    if verbose:
+        print('x_labeled:', np.shape(x_labeled), 'y_labeled:', np.shape(y_labeled))
+
+    model = MRGAN(X_train.shape[1], batch_size=batch_size, dtype=dtype, seed=int(rs.randint(1 << 31)), device=device)
+    if verbose:
+        print('Epochs:', epochs)
+        print('Batch size:', batch_size)
+        print('Training batches per epoch:', X_train.shape[0] // batch_size)
+        print('Testing batches per epoch:', X_test.shape[0] // batch_size)
+    hist = model.fit(x_labeled, y_labeled, X_train, epochs=epochs, verbose=1 if verbose else 0,
+                     validation_data=(X_test, y_test), x_unlabeled_pool=x_unlabeled, rng=rs)
+    testerror = model.evaluate(X_test, y_test)                     # mr_gan.py:230 -- whole test set in one call
+    if verbose:
+        print('Test error:', testerror, hist[-1]['test_err'] if hist else float('nan'))
+        sys.stdout.flush()
+    model.engine.close()
+    return testerror
+
+
+def _logmel(contact, sr=48000, n_mels=128):
+    from mr_gan_amd.melspec import log_melspectrogram
+    return log_melspectrogram(np.asarray(contact, dtype=np.float64), sr=sr, n_mels=n_mels)
+
+
+def dataset(modalities=0, forcetempTime=4, contactmicTime=0.2, leaveObjectOut=False, verbose=False,
+            data_dir='data_processed'):
+    """mr_gan.py:23-71.  Reads the MREO pickles written by processdata.py (not shipped with the reference;
+    README.md:7-11) and concatenates the modality vectors in the reference's fixed order."""
+    X, y = [], []
+    objects = dict()
+    for m, material in enumerate(MATERIALS):
+        if verbose:
+            print('Processing', material)
+            sys.stdout.flush()
+        fname = os.path.join(data_dir, 'processed_0.1sbefore_%s_times_%.2f_%.2f.pkl' % (material, forcetempTime, contactmicTime))
+        with open(fname, 'rb') as f:
+            allData = pickle.load(f, encoding='latin1')          # py2 cPickle files (others/mr_nn_activation_map_py3.py:33)
+        for objName, objData in allData.items():
+            if leaveObjectOut:
+                objects[objName] = {'x': [], 'y': []}
+                X = objects[objName]['x']
+                y = objects[objName]['y']
+            for i in range(len(objData['temperature'])):
+                y.append(m)
+                if modalities > 2:
+                    log_S = _logmel(objData['contact'][i])       # mr_gan.py:42-47
+                f0, f1, temp = list(objData['force0'][i]), list(objData['force1'][i]), list(objData['temperature'][i])
+                if modalities == 0:
+                    X.append(f0 + f1)
+                elif modalities == 1:
+                    X.append(temp)
+                elif modalities == 2:
+                    X.append(temp + f0 + f1)
+                elif modalities == 3:
+                    X.append(log_S.flatten())
+                elif modalities == 4:
+                    X.append(temp + log_S.flatten().tolist())
+                elif modalities == 5:
+                    X.append(temp + f0 + f1 + log_S.flatten().tolist())
+                elif modalities == 6:
+                    X.append(f0 + f1 + log_S.flatten().tolist())
+    if leaveObjectOut:
+        return objects
+    X = np.array(X)
+    y = np.array(y)
+    if verbose:
+        print('X:', np.shape(X), 'y:', np.shape(y))
+    return X, y
+
+
+def _kfold(X, y, run, verbose):
+    from sklearn.model_selection import StratifiedKFold
+    errors = []
+    skf = StratifiedKFold(n_splits=6, shuffle=True)              # mr_gan.py:255
+    for trainIdx, testIdx in skf.split(X, y):
+        errors.append(run([X[trainIdx], X[testIdx], y[trainIdx], y[testIdx]]))
+        print('Test error:', errors[-1], 'Test accuracy:', 1.0 - errors[-1])
+        sys.stdout.flush()
+    print('Average error:', np.mean(errors), 'Average accuracy:', np.mean(1.0 - np.array(errors)))
+    sys.stdout.flush()
+    return errors
+
+
+def main(argv=None, dataset_fn=dataset, mr_gan_fn=mr_gan):
+    parser = argparse.ArgumentParser(description='Semi-supervised learning with GANs for material recognition on haptic data.')
+    parser.add_argument('-t', '--tables', nargs='+', help='[Required] Tables to recompute', required=True)
+    parser.add_argument('-v', '--verbose', help='Verbose', action='store_true')
+    parser.add_argument('--epochs', type=int, default=100)
+    parser.add_argument('--dtype', default='float32')
+    args = parser.parse_args(argv)
+    kw = dict(epochs=args.epochs, dtype=args.dtype, verbose=args.verbose)
+
+    if '1' in args.tables:                                         # mr_gan.py:244-261
+        print('\n', '-' * 25, 'Testing various amounts of labeled training data', '-' * 25)
+        print('-' * 100)
+        for modality in range(len(MODALITIES)):
+            print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
+            X, y = dataset_fn(modalities=modality)
+            for percent in [1, 2, 4, 8, 16, 50, 100]:
+                print('-' * 15, 'Percentage of training data labeled: %d%%' % percent, '-' * 15)
+                _kfold(X, y, lambda sets: mr_gan_fn(None, None, percentlabeled=percent, trainTestSets=sets, **kw), args.verbose)
+
+    if '3' in args.tables:                                         # mr_gan.py:263-283
+        print('\n', '-' * 25, 'Testing generalization with leave-one-object-out validation', '-' * 25)
+        print('-' * 100)
+        for modality in [2, 5]:
+            print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
+            objects = dataset_fn(modalities=modality, leaveObjectOut=True)
+            for percent in [1, 4, 16, 50, 100]:
+                print('-' * 15, 'Percentage of training data labeled: %d%%' % percent, '-' * 15)
+                errors = []
+                for objName, objData in objects.items():
+                    Xtest = np.array(objData['x'])
+                    ytest = np.array(objData['y'])
+                    Xtrain = np.array(list(itertools.chain.from_iterable([d['x'] for n, d in objects.items() if n != objName])))
+                    ytrain = np.array(list(itertools.chain.from_iterable([d['y'] for n, d in objects.items() if n != objName])))
+                    errors.append(mr_gan_fn(None, None, percentlabeled=percent, trainTestSets=[Xtrain, Xtest, ytrain, ytest], **kw))
+                    print(objName, 'Test error:', errors[-1], 'Test accuracy:', 1.0 - errors[-1])
+                    sys.stdout.flush()
+                print('Average leave-one-object-out error:', np.mean(errors), 'Average accuracy:', np.mean(1.0 - np.array(errors)))
+                sys.stdout.flush()
+
+    if '5' in args.tables:                                         # mr_gan.py:285-318
+        print('\n', '-' * 25, 'Testing various lengths of contact time in training data', '-' * 25)
+        print('-' * 100)
+        for modality in range(3):
+            print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
+            for ftTime in [4, 3, 2, 1, 0.5, 0.2, 0.1]:
+                print('-' * 15, 'Length of training data: %.1fs' % ftTime, '-' * 15)
+                X, y = dataset_fn(modalities=modality, forcetempTime=ftTime)
+                _kfold(X, y, lambda sets: mr_gan_fn(None, None, percentlabeled=100, trainTestSets=sets, **kw), args.verbose)
+        print('\n', '-' * 25, 'Testing various lengths of contact time in training data', '-' * 25)
+        print('-' * 100)
+        print('-' * 25, MODALITIES[3], 'modality', '-' * 25)
+        for cTime in [1, 0.7, 0.5, 0.3, 0.2, 0.1, 0.05]:
+            print('-' * 15, 'Length of training data: %.1fs' % cTime, '-' * 15)
+            X, y = dataset_fn(modalities=3, contactmicTime=cTime)
+            _kfold(X, y, lambda sets: mr_gan_fn(None, None, percentlabeled=100, trainTestSets=sets, **kw), args.verbose)
+
+    if '6' in args.tables:                                         # mr_gan.py:320-341
+        print('\n', '-' * 25, 'Testing performance as quantity of unlabeled data increases', '-' * 25)
+        print('-' * 100)
+        for modality in [2, 5]:
+            print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
+            X, y = dataset_fn(modalities=modality)
+            for percentlabeled in [4]:
+                print('-' * 15, 'Percentage of training data labeled: %d%%' % percentlabeled, '-' * 15)
+                for percentunlabeled in [0, 4, 8, 16, 32, 64, 100 - percentlabeled]:
+                    print('-' * 15, 'Percentage of training data unlabeled: %d%%' % percentunlabeled, '-' * 15)
+                    _kfold(X, y, lambda sets: mr_gan_fn(None, None, percentlabeled=percentlabeled,
+                                                        percentunlabeled=percentunlabeled, trainTestSets=sets, **kw), args.verbose)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,90 @@
+"""Shared builders for the parity tests: one seeded problem, run through the CPU oracle.
+
+Conventions the HIP path and these tests share (documented in DESIGN.md):
+  * layer noise and z come from the device generator restated in oracle.device_normal, keyed by
+    (seed, site, segment, sub-step) where sub-step = Keras `iterations` before the call;
+  * D-step segments: 0 labeled, 1 unlabeled, 2 generated;  G-step segments: 0 generated, 1 real.
+"""
+import numpy as np
+
+from oracle import mrgan_oracle as O
+
+SEED = 0x5EED5EED
+
+
+def layer_dims(D):
+    return (D,) + O.D_HIDDEN
+
+
+def noise_set(seed, seg, step, B, D, row0=0, dtype=np.float64):
+    dims = layer_dims(D)
+    return [O.device_normal(seed, l, seg, step, B, dims[l], row0=row0, dtype=dtype) for l in range(5)]
+
+
+def draw_z(seed, step, B, row0=0, dtype=np.float64):
+    return O.device_normal(seed, O.SITE_Z, 0, step, B, O.NOISE_SIZE, row0=row0, dtype=dtype)
+
+
+class Case(object):
+    """A reproducible training problem + its oracle trajectory."""
+
+    def __init__(self, D=16, B=50, steps=3, seed=7, noise_seed=SEED, dtype=np.float64, device_z=False):
+        rng = np.random.default_rng(seed)
+        self.D, self.B, self.steps, self.noise_seed = D, B, steps, noise_seed
+        g, d = O.init_params(D, seed=seed, dtype=dtype)
+        # non-trivial biases / BN affine so every path carries signal
+        g = [p + 0.05 * rng.standard_normal(p.shape).astype(dtype) for p in g]
+        d = [p + 0.05 * rng.standard_normal(p.shape).astype(dtype) for p in d]
+        self.g0, self.d0 = [p.copy() for p in g], [p.copy() for p in d]
+        self.x_lab = rng.standard_normal((steps, B, D)).astype(np.float32)
+        self.labels = rng.integers(0, O.NUM_CLASSES, (steps, B)).astype(np.int32)
+        self.x_unl = rng.standard_normal((steps, B, D)).astype(np.float32)
+        self.x_unl2 = rng.standard_normal((steps, B, D)).astype(np.float32)
+        self.z1 = None if device_z else rng.standard_normal((steps, B, O.NOISE_SIZE)).astype(np.float32)
+        self.z2 = None if device_z else rng.standard_normal((steps, B, O.NOISE_SIZE)).astype(np.float32)
+        self.probe = rng.standard_normal((64, D)).astype(np.float32)
+        self.dtype = dtype
+
+    def disc_inputs(self, t, it, rows=None, row0=0):
+        """numpy inputs of D sub-step t executed at Keras iteration `it` (optionally a row shard)."""
+        B = self.B
+        sl = slice(row0, row0 + (rows or B))
+        nB = rows or B
+        z = self.z1[t][sl] if self.z1 is not None else draw_z(self.noise_seed, it, nB, row0)
+        return dict(x_lab=self.x_lab[t][sl].astype(self.dtype), labels=self.labels[t][sl],
+                    x_unl=self.x_unl[t][sl].astype(self.dtype), z=np.asarray(z, self.dtype),
+                    n_lab=noise_set(self.noise_seed, 0, it, nB, self.D, row0, self.dtype),
+                    n_unl=noise_set(self.noise_seed, 1, it, nB, self.D, row0, self.dtype),
+                    n_fake=noise_set(self.noise_seed, 2, it, nB, self.D, row0, self.dtype))
+
+    def gen_inputs(self, t, it, rows=None, row0=0):
+        B = self.B
+        sl = slice(row0, row0 + (rows or B))
+        nB = rows or B
+        z = self.z2[t][sl] if self.z2 is not None else draw_z(self.noise_seed, it, nB, row0)
+        return dict(x_unl=self.x_unl2[t][sl].astype(self.dtype), z=np.asarray(z, self.dtype),
+                    n_fake=noise_set(self.noise_seed, 0, it, nB, self.D, row0, self.dtype),
+                    n_real=noise_set(self.noise_seed, 1, it, nB, self.D, row0, self.dtype))
+
+    def run_oracle(self):
+        orc = O.MRGANOracle(self.g0, self.d0)
+        out = dict(disc=[], gen=[], logits0=orc.predict_logits(self.probe.astype(self.dtype)))
+        for t in range(self.steps):
+            out['disc'].append(orc.disc_step(**self.disc_inputs(t, orc.adam.iterations)))
+            out['gen'].append(orc.gen_step(**self.gen_inputs(t, orc.adam.iterations)))
+        out['logits'] = orc.predict_logits(self.probe.astype(self.dtype))
+        out['g'], out['d'] = orc.g, orc.d
+        out['oracle'] = orc
+        return out
+
+
+def rel_err(a, ref):
+    """scale-relative error: max |a - ref| / max |ref|"""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.max(np.abs(a - ref)) / (np.max(np.abs(ref)) + 1e-300))
+
+
+def update_rel_err(w, w_ref, w0):
+    """error of a weight tensor relative to the size of the update that produced it"""
+    w, w_ref, w0 = [np.asarray(x, np.float64) for x in (w, w_ref, w0)]
+    return float(np.linalg.norm(w - w_ref) / (np.linalg.norm(w_ref - w0) + 1e-300))
