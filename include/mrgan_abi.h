@@ -133,6 +133,14 @@ int mrgan_predict_logits(mrgan_handle* h, const float* x_dev, const int32_t* idx
  * last loss_gen.  reset != 0 zeroes the sums afterwards. */
 int mrgan_read_metrics(mrgan_handle* h, float* out8_host, int reset, mrgan_stream stream);
 
+/* Per-launch timing with hipEvent pairs recorded on the launch stream (bench.py's live roofline figure).
+ * While profiling is on, mrgan_train_pair launches eagerly (no graph replay).  ms / launches have
+ * MRGAN_PROF_NCAT entries: summed kernel time and launch count per category since mrgan_profile_begin. */
+enum { MRGAN_PROF_GEMM_FWD = 0, MRGAN_PROF_GEMM_DX = 1, MRGAN_PROF_GEMM_DW = 2, MRGAN_PROF_STAGE = 3, MRGAN_PROF_BN = 4,
+       MRGAN_PROF_HEAD = 5, MRGAN_PROF_FM = 6, MRGAN_PROF_ADAM = 7, MRGAN_PROF_OTHER = 8, MRGAN_PROF_NCAT = 9 };
+int mrgan_profile_begin(mrgan_handle* h);
+int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, float* ms, int32_t* launches);
+
 /* diagnostics used by the parity tests */
 int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,
                       float* out_dev, mrgan_stream stream);

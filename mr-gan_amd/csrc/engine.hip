@@ -60,6 +60,8 @@ struct Dense {
     float* slabs; int splits;   // weight-gradient slabs [nseg*splits][Kp][Np]
 };
 
+struct ProfRec { int cat; hipEvent_t e0, e1; };
+
 struct Arena {
     char* base = nullptr; size_t off = 0, cap = 0;
     template <typename T> T* take(size_t n) {
@@ -103,6 +105,9 @@ struct mrgan_handle {
     float *dw6_part, *db6_part, *dbf_part, *loss_part;
     int nblk_head, bnb_rows_per_block, bnb_blocks;
     AdamTile *tiles_g_dev, *tiles_d_dev; int ntiles_g, ntiles_d;
+
+    // per-launch hipEvent profiling (bench.py's live roofline measurement)
+    bool prof; std::vector<ProfRec> prof_recs;
 
     // graph replay of (D step, G step)
     hipGraphExec_t graph_exec; bool graph_ready; int graph_cur; mrgan_disc_args graph_d; mrgan_gen_args graph_g;
@@ -333,10 +338,34 @@ int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n,
 }
 
 // ------------------------------------------------------------------------------------------------
+// optional per-launch timing: one hipEvent pair per launch, on the launch stream
+// ------------------------------------------------------------------------------------------------
+int prof_begin(mrgan_handle* h, int cat, hipStream_t s) {
+    if (!h->prof) return -1;
+    ProfRec r;
+    r.cat = cat;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+    hipEventRecord(r.e0, s);
+    h->prof_recs.push_back(r);
+    return (int)h->prof_recs.size() - 1;
+}
+void prof_end(mrgan_handle* h, int i, hipStream_t s) {
+    if (i >= 0) hipEventRecord(h->prof_recs[i].e1, s);
+}
+#define PROF(cat, call)                      \
+    do {                                     \
+        const int pi_ = prof_begin(h, cat, s); \
+        CHK(call);                           \
+        prof_end(h, pi_, s);                 \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
 // GEMM call sites
 // ------------------------------------------------------------------------------------------------
 int run_gemm(mrgan_handle* h, int epi, const GemmArgs& g, hipStream_t s) {
-    return h->bf16 ? launch_gemm_bf16(epi, g, s) : launch_gemm_f32(epi, g, s);
+    const int cat = epi == EPI_FWD ? MRGAN_PROF_GEMM_FWD : epi == EPI_DX ? MRGAN_PROF_GEMM_DX : MRGAN_PROF_GEMM_DW;
+    PROF(cat, h->bf16 ? launch_gemm_bf16(epi, g, s) : launch_gemm_f32(epi, g, s));
+    return 0;
 }
 
 Epi base_epi(mrgan_handle* h) {
@@ -412,7 +441,8 @@ int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t 
         a.step_out = h->step_out; a.accum = h->accum;
         a.flat_tail = h->flat_d + h->flat_d_n;
     }
-    return launch_adam(a, s);
+    PROF(MRGAN_PROF_ADAM, launch_adam(a, s));
+    return 0;
 }
 
 // generator forward up to the BatchNorm statistics (phase *_GEN) and from there to the fake rows
@@ -421,8 +451,8 @@ int gen_fwd_head(mrgan_handle* h, hipStream_t s) {
                   true, s));
     if (h->sync_stats) {
         const int n = h->g[0].Np;
-        CHK(launch_colsum_finalize(h->cs_bn1, h->tiles_m, n, n, h->r_bn_stats, s));
-        CHK(launch_colsum_finalize(h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats + n, s));
+        PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_bn1, h->tiles_m, n, n, h->r_bn_stats, s));
+        PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats + n, s));
     }
     return 0;
 }
@@ -435,7 +465,7 @@ int gen_fwd_tail(mrgan_handle* h, int fake_seg_slot, uint32_t fake_seg_id, hipSt
     else { b.cs1 = h->cs_bn1; b.cs2 = h->cs_bn2; b.npart = h->tiles_m; }
     b.ldcs = n; b.count = (float)h->Bg; b.eps = h->cfg.bn_eps;
     b.gamma = h->gt[2].p; b.beta = h->gt[3].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
-    CHK(launch_bn_apply(h->bf16, b, s));
+    PROF(MRGAN_PROF_BN, launch_bn_apply(h->bf16, b, s));
     CHK(dense_fwd(h, h->g[1], h->hbn, h->B, 1, h->h2, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_NONE, nullptr, nullptr, true, s));
     // generator output + GaussianNoise(sigma0) = the discriminator's noisy input rows of the fake segment
     void* out = rowptr(h, h->xin[0], (long)fake_seg_slot * h->S, h->Dp);
@@ -485,7 +515,7 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         data_seg(st.s[0], h, a->x_lab_dev, a->idx_lab_dev, a->ld_x_lab, 0, 0, a->stream_mode);
         data_seg(st.s[1], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);
         stage_common(st, h, a->z_dev, a->stream_mode, 0, 2);
-        CHK(launch_stage(h->bf16, st, s));
+        PROF(MRGAN_PROF_STAGE, launch_stage(h->bf16, st, s));
         CHK(gen_fwd_head(h, s));
     } else if (phase == MRGAN_D_MAIN) {
         CHK(gen_fwd_tail(h, 2, 2, s));
@@ -502,7 +532,7 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         hd.dpre = h->dpre[4]; hd.dpre_bs = (long)h->S * h->Fp; hd.ldd = h->Fp;
         hd.dw_part = h->dw6_part; hd.db_part = h->db6_part; hd.dbf_part = h->dbf_part; hd.ldbf = h->Fp;
         hd.loss_part = h->loss_part;
-        CHK(launch_head(h->bf16, hd, s));
+        PROF(MRGAN_PROF_HEAD, launch_head(h->bf16, hd, s));
         for (int l = 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 3, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_SUM, h->cs_db[l - 1], nullptr, s));
@@ -525,14 +555,14 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         memset(&st, 0, sizeof st);
         data_seg(st.s[0], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);   // real rows -> slot 1
         stage_common(st, h, a->z_dev, a->stream_mode, a->stream_mode ? 1 : 0, 1);
-        CHK(launch_stage(h->bf16, st, s));
+        PROF(MRGAN_PROF_STAGE, launch_stage(h->bf16, st, s));
         CHK(gen_fwd_head(h, s));
     } else if (phase == MRGAN_G_FEAT) {
         CHK(gen_fwd_tail(h, 0, 0, s));                                                          // fake rows -> slot 0
         CHK(disc_fwd_train(h, 2, true, s));
         if (h->sync_stats) {
-            CHK(launch_colsum_finalize(h->cs_f, tm, h->Fp, h->Fp, h->r_fm, s));
-            CHK(launch_colsum_finalize(h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm + h->Fp, s));
+            PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_f, tm, h->Fp, h->Fp, h->r_fm, s));
+            PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm + h->Fp, s));
         }
     } else if (phase == MRGAN_G_BWD) {
         FmArgs f;
@@ -542,7 +572,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         f.ldcs = h->Fp; f.count = (float)h->Bg; f.feat = h->Fp; f.feat_valid = h->F;
         f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B; f.rows_per_block = 32;
         f.loss_out = h->step_out + 3; f.accum = h->accum + 3;
-        CHK(launch_fm(h->bf16, f, s));
+        PROF(MRGAN_PROF_FM, launch_fm(h->bf16, f, s));
         for (int l = 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 1, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_NONE, nullptr, nullptr, s));
@@ -554,8 +584,8 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         CHK(dense_dx(h, h->g[1], h->dpre2g, B, 1, h->dhbn, ACT_LINEAR, h->g[0].N, nullptr, 0, h->h1, CS_SUM_XHAT, h->cs_dbeta,
                      h->cs_dgamma, s));
         if (h->sync_stats) {
-            CHK(launch_colsum_finalize(h->cs_dbeta, tm, N1p, N1p, h->r_bn_bwd, s));
-            CHK(launch_colsum_finalize(h->cs_dgamma, tm, N1p, N1p, h->r_bn_bwd + N1p, s));
+            PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_dbeta, tm, N1p, N1p, h->r_bn_bwd, s));
+            PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_dgamma, tm, N1p, N1p, h->r_bn_bwd + N1p, s));
         }
     } else if (phase == MRGAN_G_TAIL) {
         BnBwdArgs b;
@@ -565,7 +595,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         else { b.cs1 = h->cs_dbeta; b.cs2 = h->cs_dgamma; b.npart = tm; }
         b.ldcs = N1p; b.count = (float)h->Bg; b.gamma = h->gt[2].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
         b.db_part = h->db1g_part; b.rows_per_block = h->bnb_rows_per_block;
-        CHK(launch_bn_bwd(h->bf16, b, s));
+        PROF(MRGAN_PROF_BN, launch_bn_bwd(h->bf16, b, s));
         CHK(dense_dw(h, h->g[2], h->h2, h->dxfake, B, 1, s));
         CHK(dense_dw(h, h->g[1], h->hbn, h->dpre2g, B, 1, s));
         CHK(dense_dw(h, h->g[0], h->zbuf, h->dpre1g, B, 1, s));
@@ -600,7 +630,7 @@ int eval_rows(mrgan_handle* h, const float* x, const int32_t* idx, long ld, cons
         sg.src = idx ? x : x + r0 * ld; sg.idx = idx ? idx + r0 : nullptr; sg.ld = ld; sg.rows = rows;
         sg.cols = h->cfg.d_in; sg.cols_pad = h->Dp; sg.out = h->xin[0]; sg.ldo = h->Dp;
         st.nseg = 1; st.seed = h->cfg.seed; st.cur = h->state + h->cur; st.next = nullptr;
-        CHK(launch_stage(h->bf16, st, s));
+        PROF(MRGAN_PROF_STAGE, launch_stage(h->bf16, st, s));
         for (int l = 0; l < 5; ++l) {
             // one "segment" of `rows` contiguous rows: batch stride is irrelevant with nb = 1
             CHK(dense_fwd(h, h->d[l], h->xin[l], rows, 1, l < 4 ? h->xin[l + 1] : h->feat, ACT_RELU, 0.f, 0, 0, nullptr, 0, CS_NONE,
@@ -615,7 +645,7 @@ int eval_rows(mrgan_handle* h, const float* x, const int32_t* idx, long ld, cons
         if (!labels) hd.seg_kind[0] = HEAD_LOGITS;
         hd.st = h->state + h->cur; hd.labels_stream = 0;
         hd.logits = h->logits; hd.err_count = labels ? h->err_count : nullptr;
-        CHK(launch_head(h->bf16, hd, s));
+        PROF(MRGAN_PROF_HEAD, launch_head(h->bf16, hd, s));
         if (logits_out)
             HIPCHK(hipMemcpy2DAsync(logits_out + r0 * h->cfg.num_classes, sizeof(float) * h->cfg.num_classes, h->logits,
                                     sizeof(float) * KMAX, sizeof(float) * h->cfg.num_classes, rows, hipMemcpyDeviceToDevice, s));
@@ -682,7 +712,7 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
     }
     h->ws_bytes = need;
     layout(h, h->ws, &need);
-    h->cur = 0; h->graph_ready = false; h->graph_exec = nullptr;
+    h->cur = 0; h->graph_ready = false; h->graph_exec = nullptr; h->prof = false;
     if (init_kernel_attributes() != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "hipFuncSetAttribute failed"); }
 #define CREATE_CHK(x)                                           \
     do {                                                        \
@@ -814,7 +844,7 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
     if (!r) r = check_gen_args(h, g);
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
-    const bool want_graph = (h->cfg.flags & MRGAN_FLAG_GRAPH) && d->stream_mode && g->stream_mode && !h->flat_grads && !h->sync_stats;
+    const bool want_graph = !h->prof && (h->cfg.flags & MRGAN_FLAG_GRAPH) && d->stream_mode && g->stream_mode && !h->flat_grads && !h->sync_stats;
     if (!want_graph) {
         r = mrgan_disc_step(h, d, 0, -1, nullptr, stream);
         if (!r) r = mrgan_gen_step(h, g, 0, -1, nullptr, stream);
@@ -888,6 +918,26 @@ int mrgan_read_metrics(mrgan_handle* h, float* out8, int reset, mrgan_stream str
     HIPCHK(hipMemcpyAsync(out8 + 4, h->step_out, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (reset) HIPCHK(hipMemsetAsync(h->accum, 0, 4 * sizeof(float), s));
     HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int mrgan_profile_begin(mrgan_handle* h) {
+    if (!h) return fail(-1, "null handle");
+    h->prof = true;
+    return 0;
+}
+
+int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, float* ms, int32_t* launches) {
+    if (!h || !ms || !launches) return fail(-1, "null argument");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < MRGAN_PROF_NCAT; ++i) { ms[i] = 0.f; launches[i] = 0; }
+    for (auto& r : h->prof_recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms[r.cat] += t; launches[r.cat] += 1; }
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    h->prof_recs.clear();
+    h->prof = false;
     return 0;
 }
 

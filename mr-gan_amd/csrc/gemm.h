@@ -78,6 +78,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         for (int ni = 0; ni < NR; ++ni) {
             const int col = col_blk + (wn * NR + ni) * 32 + lc;
             const bool colvalid = col < e.n_valid;
+            const bool colin = col < g.N;              // N is a multiple of 64, the block tile is 128 wide
             float bias = 0.f, mu = 0.f, rstd = 0.f;
             if constexpr (EPI == EPI_FWD) { if (colvalid && e.bias) bias = e.bias[col]; }
             if constexpr (EPI == EPI_DX) {
@@ -105,27 +106,27 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             if (!colvalid) v = 0.f;
                             if (e.act == ACT_RELU && mask) {
                                 const unsigned long long bal = __ballot(v > 0.f);
-                                if (lc == 0 && rowvalid)
+                                if (lc == 0 && rowvalid && colin)
                                     mask[(long)row * e.ldm + (col >> 5)] = lh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
                             }
                             if (rowvalid) { cs1[ni] += v; cs2[ni] += v * v; }
                             if (colvalid) v += e.sigma * nz[j];
                         } else {
                             if (e.act == ACT_RELU) {
-                                const uint32_t w = rowvalid ? mask[(long)row * e.ldm + (col >> 5)] : 0u;
+                                const uint32_t w = (rowvalid && colin) ? mask[(long)row * e.ldm + (col >> 5)] : 0u;
                                 v = ((w >> (col & 31)) & 1u) ? v : 0.f;
                             } else if (e.act == ACT_SOFTPLUS) {
-                                const float hv = rowvalid ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
+                                const float hv = (rowvalid && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
                                 v *= -expm1f(-hv);            // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
                             }
                             if (!colvalid || !rowvalid) v = 0.f;
                             cs1[ni] += v;
-                            if (e.cs_mode == CS_SUM_XHAT && rowvalid) {
+                            if (e.cs_mode == CS_SUM_XHAT && rowvalid && colin) {
                                 const float h1 = Elem<T>::to_f32(hprev[(long)row * e.ldh + col]);
                                 cs2[ni] += v * (h1 - mu) * rstd;
                             }
                         }
-                        if (rowvalid) out[(long)row * e.ldo + col] = Elem<T>::from_f32(v);
+                        if (rowvalid && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(v);
                     }
                 }
             }

@@ -103,9 +103,11 @@ __device__ __forceinline__ bf16x8 ks_frag(const char* tile, int fb, int ks, int 
     const int f0 = fb + (g4 & 1) * 16;
     const int m0 = ks * 16 + (g4 >> 1) * 8;
     const char* a0 = tile + (m0 + q) * KS_PITCH + (f0 + 4 * p) * 2;
-    const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-    const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * KS_PITCH));
-    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    // (the v4i16 form: per-element use of the v4bf16 form's result is mis-folded by hipcc 7.2)
+    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * KS_PITCH));
+    const s16x8 t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, t);
 }
 
 __global__ __launch_bounds__(256) void gemm_bf16_ks_kernel(const GemmArgs g) {
@@ -178,13 +180,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_kernel(const GemmArgs g) {
     epilogue<__bf16, EPI_SLAB, 2, 2, 2>(acc, g, batch, split, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BN);
 }
 
-// diagnostic: what ds_read_b64_tr_b16 returns to each lane for a known [16][160] u16 image (value = row<<8 | col)
+// diagnostic: out[0..511]  = what ds_read_b64_tr_b16 returns when lane l supplies the address of u16 elements
+//                            4l..4l+3 of a linear image whose element i holds the value i;
+//             out[512..1023] = ks_frag() on a [16][160] image whose element (row, col) holds row<<8 | col.
 __global__ void tr_probe_kernel(unsigned short* out) {
     __shared__ __attribute__((aligned(16))) unsigned short img[16 * 160];
-    for (int i = threadIdx.x; i < 16 * 160; i += 64) img[i] = (unsigned short)(((i / 160) << 8) | (i % 160));
+    const int l = threadIdx.x;
+    for (int i = l; i < 16 * 160; i += 64) img[i] = (unsigned short)i;
     __syncthreads();
-    const bf16x8 f = ks_frag((const char*)img, 0, 0, threadIdx.x);
-    for (int j = 0; j < 8; ++j) out[threadIdx.x * 8 + j] = __builtin_bit_cast(unsigned short, f[j]);
+    const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)((const char*)img + l * 8));
+    for (int j = 0; j < 4; ++j) out[l * 8 + j] = (unsigned short)t[j];
+    for (int j = 4; j < 8; ++j) out[l * 8 + j] = 0;
+    __syncthreads();
+    for (int i = l; i < 16 * 160; i += 64) img[i] = (unsigned short)(((i / 160) << 8) | (i % 160));
+    __syncthreads();
+    const s16x8 f = __builtin_bit_cast(s16x8, ks_frag((const char*)img, 0, 0, l));
+    for (int j = 0; j < 8; ++j) out[512 + l * 8 + j] = (unsigned short)f[j];
 }
 }  // namespace
 

@@ -1,0 +1,91 @@
+"""Data-parallel driver: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" in the CPU tests), gradients and batch statistics exchanged between the phases of
+include/mrgan_abi.h.
+
+The reference is single-process; this is new.  Every rank holds a replica of the weights
+and Adam state and processes batch/world rows of each of the labeled / unlabeled / generated streams.
+Two quantities of the path are batch-global rather than per-sample sums -- the BatchNorm statistics of
+the generator (mr_gan.py:112) and the feature-matching moments (mr_gan.py:152-153) -- so with
+exact=True they are all-reduced too and W ranks at batch B/W reproduce the single-GPU batch-B step up
+to summation order.  exact=False keeps them per-shard (a different, cheaper algorithm; labelled
+"local_stats" wherever it is reported).
+
+Exchanges per (D, G) pair, all sums of fp32 buffers that live inside the library workspace:
+    D: [BN stats 2xN1p]  ->  flat D gradients (+4 scalars)
+    G: [BN stats]  [FM moments 2xFp]  [BN-backward sums 2xN1p]  ->  flat G gradients (+4 scalars)
+"""
+import torch.distributed as dist
+
+from mr_gan_amd import engine as E
+
+
+class PhaseBackend(object):
+    """What DataParallel needs from an engine: run phases, expose the exchange regions as tensors.
+    Engine satisfies it; the CPU tests supply an oracle-backed stand-in to exercise the protocol."""
+
+    def disc_phase(self, args, phase):
+        raise NotImplementedError
+
+    def gen_phase(self, args, phase):
+        raise NotImplementedError
+
+    def region(self, which):
+        raise NotImplementedError
+
+
+class EngineBackend(PhaseBackend):
+    def __init__(self, engine):
+        self.engine = engine
+
+    def disc_phase(self, args, phase):
+        return self.engine.disc_step(args, phase, phase, want_outputs=False)
+
+    def gen_phase(self, args, phase):
+        return self.engine.gen_step(args, phase, phase, want_outputs=False)
+
+    def region(self, which):
+        return self.engine.region(which)
+
+
+class DataParallel(object):
+    def __init__(self, backend, exact=True, group=None):
+        self.backend = backend
+        self.exact = exact
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def _allreduce(self, which):
+        if self.world > 1:
+            dist.all_reduce(self.backend.region(which), op=dist.ReduceOp.SUM, group=self.group)
+
+    def disc_step(self, args):
+        b = self.backend
+        b.disc_phase(args, E.D_GEN)
+        if self.exact:
+            self._allreduce(E.REGION_BN_STATS)
+        b.disc_phase(args, E.D_MAIN)
+        self._allreduce(E.REGION_GRAD_D)
+        b.disc_phase(args, E.D_ADAM)
+
+    def gen_step(self, args):
+        b = self.backend
+        b.gen_phase(args, E.G_GEN)
+        if self.exact:
+            self._allreduce(E.REGION_BN_STATS)
+        b.gen_phase(args, E.G_FEAT)
+        if self.exact:
+            self._allreduce(E.REGION_FM_MOMENTS)
+        b.gen_phase(args, E.G_BWD)
+        if self.exact:
+            self._allreduce(E.REGION_BN_BWD)
+        b.gen_phase(args, E.G_TAIL)
+        self._allreduce(E.REGION_GRAD_G)
+        b.gen_phase(args, E.G_ADAM)
+
+    def train_pair(self, dargs, gargs):
+        self.disc_step(dargs)
+        self.gen_step(gargs)
+
+
+def dp_flags(exact=True):
+    return E.FLAG_FLAT_GRADS | (E.FLAG_SYNC_STATS if exact else 0)

@@ -25,8 +25,9 @@ EXPORTS = [
     "mrgan_num_tensors", "mrgan_tensor_shape", "mrgan_set_weights", "mrgan_get_weights", "mrgan_get_slot",
     "mrgan_set_slot", "mrgan_get_iterations", "mrgan_set_iterations", "mrgan_disc_step", "mrgan_gen_step",
     "mrgan_train_pair", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
-    "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm",
+    "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end",
 ]
+PROF_CATEGORIES = ["gemm_fwd", "gemm_dx", "gemm_dw", "stage", "bn", "head", "fm", "adam", "other"]
 
 
 class Config(C.Structure):
@@ -209,6 +210,7 @@ class Engine(object):
         a.x_unl, a.idx_unl, a.z = _ptr(x_unl), _ptr(idx_unl), _ptr(z)
         a.ld_x_lab, a.ld_x_unl = x_lab.stride(0), x_unl.stride(0)
         a.stream_mode = stream_mode
+        a._refs = (x_lab, labels, x_unl, z, idx_lab, idx_unl)    # the struct holds raw pointers: keep the tensors alive
         return a
 
     @staticmethod
@@ -217,6 +219,7 @@ class Engine(object):
         a.x_unl, a.idx_unl, a.z = _ptr(x_unl), _ptr(idx_unl), _ptr(z)
         a.ld_x_unl = x_unl.stride(0)
         a.stream_mode = stream_mode
+        a._refs = (x_unl, z, idx_unl)
         return a
 
     def disc_step(self, args, first=0, last=-1, want_outputs=True):
@@ -253,6 +256,16 @@ class Engine(object):
         _check(self.lib.mrgan_read_metrics(self.handle, out, 1 if reset else 0, _stream()))
         return list(out)
 
+    def profile_begin(self):
+        _check(self.lib.mrgan_profile_begin(self.handle))
+
+    def profile_end(self):
+        """-> {category: (total ms, launches)} of per-launch hipEvent timings since profile_begin"""
+        n = len(PROF_CATEGORIES)
+        ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
+        _check(self.lib.mrgan_profile_end(self.handle, _stream(), ms, cnt))
+        return {PROF_CATEGORIES[i]: (ms[i], cnt[i]) for i in range(n)}
+
     def region(self, which):
         """fp32 torch view of a workspace region (aliases library memory: used for all-reduce)."""
         p, n = C.c_void_p(), C.c_size_t()
@@ -284,6 +297,6 @@ def debug_gemm(dtype, op, a, b, bias=None, act=0, splits=1):
 
 
 def debug_tr_probe(device="cuda:0"):
-    out = torch.zeros(512, dtype=torch.int16, device=device)
+    out = torch.zeros(1024, dtype=torch.int16, device=device)
     _check(load_library().mrgan_debug_tr_probe(_ptr(out), _stream()))
-    return out.cpu().numpy().astype(np.uint16).reshape(64, 8)
+    return out.cpu().numpy().astype(np.uint16).reshape(2, 64, 8)

@@ -45,6 +45,8 @@ class MRGAN(object):
         self.cfg = cfg
         self.engine = E.Engine(cfg, device)
         self.device = self.engine.device
+        # a private HIP stream: graph capture is not permitted on the legacy default stream
+        self.stream = torch.cuda.Stream(self.device)
         self.iterations = 0
         self.history = []
         if init_weights:
@@ -78,23 +80,49 @@ class MRGAN(object):
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
 
+    def _on_stream(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(self.stream)
+
     def train_batch_disc(self, x_lab, labels, x_unl, noise=None):
+        with self._on_stream():
+            return self._train_batch_disc(x_lab, labels, x_unl, noise)
+
+    def train_batch_gen(self, x_unl, noise=None):
+        with self._on_stream():
+            return self._train_batch_gen(x_unl, noise)
+
+    def test_batch(self, x, labels):
+        with self._on_stream():
+            return self.engine.eval_error(self._dev(x), self._dev(labels, torch.int32))
+
+    def fit(self, *args, **kwargs):
+        with self._on_stream():
+            return self._fit(*args, **kwargs)
+
+    def predict_logits(self, X):
+        with self._on_stream():
+            return self.engine.predict_logits(self._dev(X)).cpu().numpy()
+
+    def evaluate(self, X, y):
+        """test_batch([0, X, y]) over the whole set (mr_gan.py:230) -> error rate."""
+        with self._on_stream():
+            return self.engine.eval_error(self._dev(X), self._dev(y, torch.int32))
+
+    def _train_batch_disc(self, x_lab, labels, x_unl, noise=None):
         a = E.Engine.disc_args(self._dev(x_lab), self._dev(labels, torch.int32), self._dev(x_unl),
                                None if noise is None else self._dev(noise))
         self._hold = a
         self.iterations += 1
         return self.engine.disc_step(a)
 
-    def train_batch_gen(self, x_unl, noise=None):
+    def _train_batch_gen(self, x_unl, noise=None):
         a = E.Engine.gen_args(self._dev(x_unl), None if noise is None else self._dev(noise))
         self.iterations += 1
         return self.engine.gen_step(a)
 
-    def test_batch(self, x, labels):
-        return self.engine.eval_error(self._dev(x), self._dev(labels, torch.int32))
-
     # ---- Keras-shaped API ---------------------------------------------------------------------------------------
-    def fit(self, x_labeled, y_labeled, x_unlabeled, epochs=100, batch_size=None, verbose=0, validation_data=None,
+    def _fit(self, x_labeled, y_labeled, x_unlabeled, epochs=100, batch_size=None, verbose=0, validation_data=None,
             x_unlabeled_pool=None, rng=None):
         """The epoch loop of mr_gan.py:183-228.
 
@@ -155,12 +183,5 @@ class MRGAN(object):
                 sys.stdout.flush()
         return self.history
 
-    def predict_logits(self, X):
-        return self.engine.predict_logits(self._dev(X)).cpu().numpy()
-
     def predict(self, X):
         return np.argmax(self.predict_logits(X), axis=1)
-
-    def evaluate(self, X, y):
-        """test_batch([0, X, y]) over the whole set (mr_gan.py:230) -> error rate."""
-        return self.engine.eval_error(self._dev(X), self._dev(y, torch.int32))

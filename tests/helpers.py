@@ -88,3 +88,9 @@ def update_rel_err(w, w_ref, w0):
     """error of a weight tensor relative to the size of the update that produced it"""
     w, w_ref, w0 = [np.asarray(x, np.float64) for x in (w, w_ref, w0)]
     return float(np.linalg.norm(w - w_ref) / (np.linalg.norm(w_ref - w0) + 1e-300))
+
+
+def frob_rel_err(a, ref):
+    """Frobenius-relative error ||a - ref|| / ||ref||"""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.linalg.norm(a - ref) / (np.linalg.norm(ref) + 1e-300))
