@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""Headline benchmark: GAN train steps/sec (labeled + unlabeled + G) at batch 4096 (BASELINE.json).
+
+One step = one discriminator sub-step (B labeled + B unlabeled + B generated rows) + one generator
+sub-step (B generated + B unlabeled rows), Adam included (mr_gan.py:204-213).  Workload = BASELINE
+config 2: synthetic N=65536 x D=512, K=6, batch 4096, bf16 MFMA with fp32 accumulate/master weights.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); per-GPU batch stays
+4096 (weak scaling) and `value` counts batch-4096 steps summed over ranks.
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live: per-launch hipEvent pairs recorded by the
+library on the launch stream over a separate profiled pass (never the timed region's numbers re-used),
+`cpu_baseline` times the CPU oracle (a port: the reference's Theano/Keras path cannot run)
+on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_flops(B, D, g_hidden=(500, 500), d_hidden=(1000, 500, 250, 250, 250), K=6, nz=100):
+    """2 FLOPs per MAC, GEMMs only, unpadded logical shapes.  Returns per-category FLOPs of
+    one (D, G) step pair: forward / input-gradient / weight-gradient products."""
+    gd = (nz,) + tuple(g_hidden) + (D,)
+    dd = (D,) + tuple(d_hidden) + (K,)
+    PG = sum(gd[i] * gd[i + 1] for i in range(3))
+    PD = sum(dd[i] * dd[i + 1] for i in range(6))
+    PD_head = dd[5] * dd[6]
+    PD_body = PD - PD_head                       # the five dense layers run as MFMA GEMMs; the 250x6 head is fused
+    FD1, FG1 = dd[0] * dd[1], gd[0] * gd[1]
+    # D step: G fwd, 3x D fwd, 3x dW, 3x dX (no dX through the first D layer)
+    d_fwd = PG + 3 * PD
+    d_dx = 3 * (PD - FD1)
+    d_dw = 3 * PD
+    # G step: G fwd, 2x feature fwd, dX through the 5 feature layers (fake rows), G dW, G dX (not through layer 1)
+    Pmid = PD_body
+    g_fwd = PG + 2 * Pmid
+    g_dx = Pmid + (PG - FG1)
+    g_dw = PG
+    tot = 2.0 * B * (d_fwd + d_dx + d_dw + g_fwd + g_dx + g_dw)
+    # what the three GEMM kernels execute (the fused head's 2*B*250*6-sized products are excluded from kernel shares)
+    head = 2.0 * B * PD_head
+    fwd = 2.0 * B * (d_fwd + g_fwd) - 3 * head
+    dx = 2.0 * B * (d_dx + g_dx) - 3 * head
+    dw = 2.0 * B * (d_dw + g_dw) - 3 * head
+    return dict(total=tot, gemm_fwd=fwd, gemm_dx=dx, gemm_dw=dw)
+
+
+def build_problem(args, rank):
+    from mr_gan_amd import select_labeled, synthetic_blobs
+    X, y = synthetic_blobs(n=args.rows, d=args.d, seed=1234 + rank)
+    mu, sd = X.mean(0), X.std(0)
+    X = ((X - mu) / sd).astype(np.float32)                           # StandardScaler (mr_gan.py:96-98)
+    xl, yl, _ = select_labeled(X, y, args.labeled_per_class)
+    return X, y, xl, yl
+
+
+def cpu_baseline(args, X, xl, yl, budget_s=15.0):
+    """The CPU oracle (numpy fp32, BLAS threads = all host cores) on the same workload, bounded sample."""
+    from oracle import mrgan_oracle as O
+    rng = np.random.default_rng(0)
+    B, D = args.batch, args.d
+    g, d = O.init_params(D, seed=1, dtype=np.float32)
+    orc = O.MRGANOracle(g, d)
+    dims = (D,) + O.D_HIDDEN
+
+    def noise():
+        return [rng.standard_normal((B, dims[l]), dtype=np.float32) for l in range(5)]
+
+    def one_step():
+        il = rng.integers(0, xl.shape[0], B)
+        iu = rng.integers(0, X.shape[0], B)
+        z = rng.standard_normal((B, O.NOISE_SIZE), dtype=np.float32)
+        orc.disc_step(xl[il], yl[il], X[iu], z, noise(), noise(), noise())
+        z = rng.standard_normal((B, O.NOISE_SIZE), dtype=np.float32)
+        orc.gen_step(X[iu], z, noise(), noise())
+    one_step()                                                        # warm-up (BLAS thread pool, page-in)
+    n, t0 = 0, time.time()
+    while True:
+        one_step()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 64:
+            break
+    dt = time.time() - t0
+    return dict(value=n / dt, unit="steps/s", cores=os.cpu_count(), kind="port",
+                sample="%d steps of the same workload (B=%d, D=%d) through oracle/mrgan_oracle.py in numpy fp32, %.1f s; "
+                       "noise generation included" % (n, B, D, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--d", type=int, default=512)
+    ap.add_argument("--rows", type=int, default=65536)
+    ap.add_argument("--labeled-per-class", type=int, default=100)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--local-stats", action="store_true", help="per-shard BN / feature-matching statistics (N > 1 only)")
+    ap.add_argument("--profile-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mr_gan_amd import engine as E
+    from mr_gan_amd.data import tiled_permutation
+    from mr_gan_amd.dist import DataParallel, EngineBackend, dp_flags
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    X, y, xl, yl = build_problem(args, rank)
+    B, D = args.batch, args.d
+    cfg = E.default_config(D, B)
+    cfg.dtype = E.BF16 if args.dtype == "bf16" else E.F32
+    cfg.seed = 1
+    cfg.rank, cfg.world = rank, world
+    cfg.flags = dp_flags(exact=not args.local_stats) if world > 1 else (0 if args.no_graph else E.FLAG_GRAPH)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        eng = E.Engine(cfg, dev)
+        # identical initial weights on every rank
+        rs = np.random.RandomState(7)
+        for net in (E.NET_G, E.NET_D):
+            ws = []
+            for i in range(eng.num_tensors(net)):
+                shp = eng.full_shape(net, i)
+                if len(shp) == 2:
+                    lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+                    ws.append(rs.uniform(-lim, lim, size=shp).astype(np.float32))
+                else:
+                    ws.append(np.ones(shp, np.float32) if (net == E.NET_G and i == 2) else np.zeros(shp, np.float32))
+            eng.set_weights(net, ws)
+        # inputs resident in HBM before the timed region; epoch index streams as in mr_gan.py:189-195
+        Xd = torch.from_numpy(X).to(dev)
+        xld = torch.from_numpy(xl).to(dev)
+        total = args.warmup + args.steps + args.profile_steps + 4
+        n_rows = total * B
+        prs = np.random.RandomState(11 + rank)
+        inds = np.concatenate([tiled_permutation(prs, xl.shape[0], X.shape[0]) for _ in range(-(-n_rows // X.shape[0]))])[:n_rows]
+        idx_lab = torch.from_numpy(inds.astype(np.int32)).to(dev)
+        lab_stream = torch.from_numpy(yl[inds].astype(np.int32)).to(dev)
+        perm = lambda: np.concatenate([prs.permutation(X.shape[0]) for _ in range(-(-n_rows // X.shape[0]))])[:n_rows].astype(np.int32)
+        idx_unl = torch.from_numpy(perm()).to(dev)
+        idx_unl2 = torch.from_numpy(perm()).to(dev)
+        dargs = E.Engine.disc_args(xld, lab_stream, Xd, None, idx_lab, idx_unl, stream_mode=1)
+        gargs = E.Engine.gen_args(Xd, None, idx_unl2, stream_mode=1)
+        eng.set_iterations(0, 0)
+        runner = DataParallel(EngineBackend(eng), exact=not args.local_stats) if world > 1 else None
+
+        def step():
+            if runner is not None:
+                runner.train_pair(dargs, gargs)
+            else:
+                eng.train_pair(dargs, gargs)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        metrics = eng.read_metrics(reset=True)
+
+        # ---- live per-kernel timing (separate pass, eager launches with hipEvent pairs) ----
+        prof = None
+        if rank == 0 or world > 1:
+            eng.profile_begin()
+            for _ in range(args.profile_steps):
+                step()
+            prof = eng.profile_end()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+    fl = algorithmic_flops(B, D)
+    peak = PEAK_TFLOPS[args.dtype]
+    # dominant kernel = the GEMM kernel with the largest share of device time in the profiled pass
+    gemm_cats = ["gemm_fwd", "gemm_dx", "gemm_dw"]
+    dom = max(gemm_cats, key=lambda c: prof[c][0])
+    dom_ms, dom_launches = prof[dom]
+    per_launch_flops = fl[dom] * args.profile_steps / max(dom_launches, 1)
+    per_launch_s = 1e-3 * dom_ms / max(dom_launches, 1)
+    achieved = per_launch_flops / per_launch_s / 1e12
+    kernel_name = {"gemm_fwd": "gemm_%s_kc_kernel<EPI_FWD>", "gemm_dx": "gemm_%s_kc_kernel<EPI_DX>",
+                   "gemm_dw": "gemm_%s_ks_kernel"}[dom] % ("bf16" if args.dtype == "bf16" else "f32")
+    if args.dtype == "f32":
+        kernel_name = "gemm_f32_kernel<%s>" % {"gemm_fwd": "EPI_FWD", "gemm_dx": "EPI_DX", "gemm_dw": "EPI_SLAB"}[dom]
+    gemm_ms = sum(prof[c][0] for c in gemm_cats) / args.profile_steps
+    all_ms = sum(v[0] for v in prof.values()) / args.profile_steps
+    roofline = {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "traffic": None,
+        "kernel": kernel_name, "launches_per_step": dom_launches / args.profile_steps,
+        "avg_launch_us": round(1e6 * per_launch_s, 2), "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3),
+        "step": {"algorithmic_gflop": round(fl["total"] / 1e9, 2), "achieved": round(fl["total"] / (elapsed / args.steps) / 1e12, 2),
+                 "frac": round(fl["total"] / (elapsed / args.steps) / 1e12 / peak, 4),
+                 "kernel_ms": {k: round(v[0] / args.profile_steps, 4) for k, v in prof.items()},
+                 "launches": {k: v[1] / args.profile_steps for k, v in prof.items()},
+                 "gemm_ms": round(gemm_ms, 4), "all_kernels_ms": round(all_ms, 4)},
+    }
+    out = {
+        "metric": "GAN train steps/sec (labeled+unlabeled+G) at batch 4096", "value": round(value, 2), "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: synthetic N=%d x D=%d, K=6, batch %d per GPU, labeled %d/class; one step = "
+                               "D sub-step (3B rows) + G sub-step (2B rows) + both Adam updates" % (args.rows, D, B, args.labeled_per_class),
+                   "global_batch": B * world, "parallelism": "dp%d" % world if world > 1 else "single",
+                   "batch_statistics": ("local_stats" if args.local_stats else "synced") if world > 1 else "n/a",
+                   "launch": "eager phases + RCCL all-reduce" if world > 1 else ("eager" if args.no_graph else "hipGraph replay")},
+        "roofline": roofline,
+        "train_metrics": {"mean_loss_lab": metrics[0] / args.steps, "mean_loss_unl": metrics[1] / args.steps,
+                          "mean_train_err": metrics[2] / args.steps, "mean_loss_gen": metrics[3] / args.steps},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, X, xl, yl)
+    print(json.dumps(out))
+    sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
