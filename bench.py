@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--local-stats", action="store_true", help="per-shard BN / feature-matching statistics (N > 1 only)")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (see mrgan_debug_ablate)")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +140,8 @@ def main():
     cfg.seed = 1
     cfg.rank, cfg.world = rank, world
     cfg.flags = dp_flags(exact=not args.local_stats) if world > 1 else (0 if args.no_graph else E.FLAG_GRAPH)
+    if args.ablate:
+        E.load_library().mrgan_debug_ablate(args.ablate)
     stream = torch.cuda.Stream(dev)
     with torch.cuda.stream(stream):
         eng = E.Engine(cfg, dev)

@@ -144,7 +144,9 @@ int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, float* ms, int32_t* 
 /* diagnostics used by the parity tests */
 int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,
                       float* out_dev, mrgan_stream stream);
-int mrgan_debug_tr_probe(uint16_t* out512_dev, mrgan_stream stream);
+int mrgan_debug_tr_probe(uint16_t* out1024_dev, mrgan_stream stream);
+/* timing experiments only (results become wrong): 1 no noise, 2 no GEMM epilogue, 4 no GEMM main loop, 8 no softplus */
+int mrgan_debug_ablate(int bits);
 /* raw GEMM entry for kernel-level parity tests: op 0 = Y = act(X W + b), 1 = dX = dY W^T, 2 = dW = X^T dY.
  * fp32 device buffers in and out (converted internally when dtype = bf16). */
 int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a_dev, const float* b_dev, const float* bias_dev,

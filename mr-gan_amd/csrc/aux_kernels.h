@@ -39,9 +39,10 @@ struct BnBwdArgs {
     const float* cs1; const float* cs2; int npart; int ldcs;   // sum(dy), sum(dy*xhat) partials
     float count;
     const float* gamma; const float* mu; const float* rstd;
-    float* db_part; int rows_per_block;                        // column sums of dpre per row block
+    float* db_part;                                            // [stat_row_blocks(rows)][ld] column sums of dpre
 };
 int launch_bn_bwd(int bf16, const BnBwdArgs& a, hipStream_t s);
+int stat_row_blocks(int rows);                                 // row blocks of the column-statistic kernels
 
 // ---- loss head (mr_gan.py:128, :146-149, :161-162): last dense + losses + their gradients ----
 enum { HEAD_LAB = 0, HEAD_UNL = 1, HEAD_FAKE = 2, HEAD_EVAL = 3, HEAD_LOGITS = 4 };
@@ -55,20 +56,22 @@ struct HeadArgs {
     float inv_count, unl_weight;               // 1/(global batch), mr_gan.py:79
     float* logits; long logits_bs;             // optional [seg][rows][KMAX]
     void* dpre; long dpre_bs; int ldd;         // dL/d(pre-activation of the feature layer), T
-    float* dw_part; float* db_part;            // [blk][feat][KMAX], [blk][KMAX]
-    float* dbf_part; int ldbf;                 // [blk][ldbf] column sums of dpre (bias grad of the feature layer)
+    float* part; long part_stride;             // per-block partial gradients: part[blk][0 .. feat*KMAX) = dW6,
+    int off_db, off_dbf;                       //   [off_db .. +KMAX) = db6, [off_dbf .. +feat) = bias grad of the feature layer
     float* loss_part;                          // [blk][4] : sum loss_lab, sum loss_unl terms, sum err, 0
     int* err_count;                            // HEAD_EVAL: integer count of argmax != label
 };
 int launch_head(int bf16, const HeadArgs& a, hipStream_t s);
+// dst[g][i] = sum over partial rows p = g, g+ngroups, ... of src[p][i]  (i < n, rows `stride` apart)
+int launch_reduce_partials(const float* src, int nsrc, long stride, int n, int ngroups, float* dst, hipStream_t s);
 int init_kernel_attributes();
 
 // ---- feature matching (mr_gan.py:152-154) ----
 struct FmArgs {
     const float* cs; int npart_fake, npart_real, ldcs;   // column partial sums of f: fake rows first, then real
-    float count; int feat, feat_valid;
+    float count, grad_scale; int feat, feat_valid;        // rows behind each mean; 1/world for per-shard statistics
     const uint32_t* mask; int ldm;                        // relu mask of the fake rows' feature layer
-    void* dpre; int ldd; int rows; int rows_per_block;
+    void* dpre; int ldd; int rows;
     float* loss_out; float* accum;                        // step scalar + epoch accumulator (block 0 only)
 };
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s);

@@ -1,15 +1,42 @@
-// Non-GEMM kernels of the mr_gan training path (HBM-bound elementwise / reduction work).
+// Non-GEMM kernels of the mr_gan training path: HBM-bound elementwise / reduction work.
+// Access pattern everywhere: 16-byte loads/stores per lane along the contiguous (feature) dimension,
+// 256-thread blocks laid out as 32 column-groups x 8 row-lanes, >= 128 blocks per launch.
 #include "aux_kernels.h"
 
 namespace mrgan {
 namespace {
 
+// 8 consecutive elements of T <-> 8 floats
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void load8<__bf16>(const __bf16* p, float v[8]) {
+    const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<__bf16>(__bf16* p, const float v[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (__bf16)v[i];
+    *(bf16x8*)p = a;
+}
+
 // =========================================================================================
 // stage: gather rows (optionally by index) of the resident fp32 matrix, add GaussianNoise(sigma)
 // (mr_gan.py:118), convert to T, zero the padding columns.  Also draws z when asked to, and --
 // being the first kernel of every sub-step -- publishes the next DevState slot.
-// thread <-> (4 row-groups of 4 rows, one column): a Philox call yields the 4 normals of one
-// row-group at one column, and consecutive lanes touch consecutive columns (coalesced).
+// thread <-> (4 rows x 4 columns): four hash calls give the 16 normals; loads are 16 B per row.
 // =========================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
@@ -24,89 +51,151 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
         *a.next = nx;
     }
     const StageSeg& sg = a.s[blockIdx.z];
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= sg.cols_pad) return;
+    const int c0 = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+    const int r4 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (c0 >= sg.cols_pad || r4 >= sg.rows) return;
     const long o = sg.stream ? (long)st.batch * sg.rows : 0;
     T* out = (T*)sg.out;
-    const bool colvalid = col < sg.cols;
-    const bool draw = colvalid && (sg.gen || sg.sigma > 0.f);
-#pragma unroll 1
-    for (int qq = 0; qq < 4; ++qq) {
-        const int r4 = (blockIdx.y * 4 + qq) * 4;
-        if (r4 >= sg.rows) break;
-        float nz[4] = {0.f, 0.f, 0.f, 0.f};
-        if (draw) normal4(a.seed, sg.site * 256u + sg.seg, st.iter, (a.row0 + (uint32_t)r4) >> 2, (uint32_t)col, nz);
+    float nz[4][4];                         // [col][row]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = r4 + j;
-            if (row >= sg.rows) break;
-            float v = 0.f;
-            if (colvalid) {
-                if (sg.gen) v = nz[j];
-                else {
-                    const long sr = sg.idx ? (long)sg.idx[o + row] : (o + row);
-                    v = sg.src[sr * sg.ld + col] + sg.sigma * nz[j];
-                }
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nz[c][j] = 0.f;
+    if (sg.gen || sg.sigma > 0.f) {
+        const uint32_t nkey = noise_key(a.seed, sg.site * 256u + sg.seg, st.iter);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c0 + c < sg.cols) normal4(nkey, (a.row0 + (uint32_t)r4) >> 2, (uint32_t)(c0 + c), nz[c]);
+    }
+    const bool vec_ok = !sg.gen && (sg.ld & 3) == 0 && ((uintptr_t)sg.src & 15) == 0 && c0 + 3 < sg.cols;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = r4 + j;
+        if (row >= sg.rows) break;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!sg.gen) {
+            const long sr = sg.idx ? (long)sg.idx[o + row] : (o + row);
+            const float* src = sg.src + sr * sg.ld + c0;
+            if (vec_ok) { const f32x4 x = *(const f32x4*)src; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; }
+            else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c0 + c < sg.cols) v[c] = src[c];
             }
-            out[(long)row * sg.ldo + col] = Elem<T>::from_f32(v);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c0 + c < sg.cols) v[c] = sg.gen ? nz[c][j] : v[c] + sg.sigma * nz[c][j];
+            else v[c] = 0.f;
+        }
+        T* dst = out + (long)row * sg.ldo + c0;
+        if constexpr (sizeof(T) == 2) {
+            bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *(bf16x4*)dst = w;
+        } else {
+            f32x4 w = {v[0], v[1], v[2], v[3]};
+            *(f32x4*)dst = w;
         }
     }
 }
 
 // =========================================================================================
-// BatchNorm forward with batch statistics (biased variance, eps inside the sqrt)
+// BatchNorm forward with batch statistics (biased variance, eps inside the sqrt).
+// Block = 256 columns x 64 rows.  Each thread first folds the per-row-tile partial sums of one
+// column into (scale, shift) in LDS, then the block streams its rows 16 bytes per lane.
 // =========================================================================================
+constexpr int RB = 64;      // rows per block of the column-statistic kernels
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= a.ld) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int p = 0; p < a.npart; ++p) { s1 += a.cs1[(long)p * a.ldcs + col]; s2 += a.cs2[(long)p * a.ldcs + col]; }
-    const float mean = s1 / a.count;
-    const float var = fmaxf(s2 / a.count - mean * mean, 0.f);
-    const float rstd = 1.0f / sqrtf(var + a.eps);
-    float scale = 0.f, shift = 0.f;
-    if (col < a.cols) { scale = a.gamma[col] * rstd; shift = a.beta[col] - mean * scale; }
-    if (blockIdx.y == 0) { a.mu[col] = mean; a.rstd[col] = rstd; }
+    __shared__ float sc[256], sh[256];
+    const int t = threadIdx.x;
+    {
+        const int col = blockIdx.x * 256 + t;
+        float scale = 0.f, shift = 0.f;
+        if (col < a.ld) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int p = 0; p < a.npart; ++p) { s1 += a.cs1[(long)p * a.ldcs + col]; s2 += a.cs2[(long)p * a.ldcs + col]; }
+            const float mean = s1 / a.count;
+            const float var = fmaxf(s2 / a.count - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + a.eps);
+            if (col < a.cols) { scale = a.gamma[col] * rstd; shift = a.beta[col] - mean * scale; }
+            if (blockIdx.y == 0) { a.mu[col] = mean; a.rstd[col] = rstd; }
+        }
+        sc[t] = scale; sh[t] = shift;
+    }
+    __syncthreads();
+    const int cg = t & 31, rl = t >> 5, c0 = blockIdx.x * 256 + cg * 8;
+    if (c0 >= a.ld) return;
     const T* h = (const T*)a.h;
     T* out = (T*)a.out;
-    const int r0 = blockIdx.y * 32, r1 = min(a.rows, r0 + 32);
-    for (int r = r0; r < r1; ++r)
-        out[(long)r * a.ld + col] = Elem<T>::from_f32(Elem<T>::to_f32(h[(long)r * a.ld + col]) * scale + shift);
+    const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
+    for (int r = blockIdx.y * RB + rl; r < r1; r += 8) {
+        float v[8];
+        load8<T>(h + (long)r * a.ld + c0, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[cg * 8 + i] + sh[cg * 8 + i];
+        store8<T>(out + (long)r * a.ld + c0, v);
+    }
 }
 
 // BatchNorm backward fused with the softplus derivative of the dense layer in front of it
 // (h = softplus(pre)  =>  sigmoid(pre) = 1 - exp(-h)); emits the bias-gradient partial sums.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= a.ld) return;
-    float dbeta = 0.f, dgamma = 0.f;
-    for (int p = 0; p < a.npart; ++p) { dbeta += a.cs1[(long)p * a.ldcs + col]; dgamma += a.cs2[(long)p * a.ldcs + col]; }
-    float g = 0.f, mu = 0.f, rs = 0.f;
-    if (col < a.cols) { g = a.gamma[col]; mu = a.mu[col]; rs = a.rstd[col]; }
-    const float k = g * rs / a.count;
-    const T* dy = (const T*)a.dy;
-    const T* h = (const T*)a.h;
-    T* dpre = (T*)a.dpre;
-    const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.rows, r0 + a.rows_per_block);
-    float acc = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const float hv = Elem<T>::to_f32(h[(long)r * a.ld + col]);
-        const float d = Elem<T>::to_f32(dy[(long)r * a.ld + col]);
-        const float xh = (hv - mu) * rs;
-        const float dh = k * (a.count * d - dbeta - xh * dgamma);
-        const float dp = dh * (-expm1f(-hv));
-        dpre[(long)r * a.ld + col] = Elem<T>::from_f32(dp);
-        acc += dp;
+    __shared__ float cA[256], cB[256], cM[256], cR[256];      // k = gamma*rstd/count ; dbeta ; mu ; rstd
+    __shared__ float cG[256];                                 // dgamma
+    __shared__ float red[8][256];
+    const int t = threadIdx.x;
+    {
+        const int col = blockIdx.x * 256 + t;
+        float dbeta = 0.f, dgamma = 0.f, g = 0.f, mu = 0.f, rs = 0.f;
+        if (col < a.ld) {
+            for (int p = 0; p < a.npart; ++p) { dbeta += a.cs1[(long)p * a.ldcs + col]; dgamma += a.cs2[(long)p * a.ldcs + col]; }
+            if (col < a.cols) { g = a.gamma[col]; mu = a.mu[col]; rs = a.rstd[col]; }
+        }
+        cA[t] = g * rs / a.count; cB[t] = dbeta; cG[t] = dgamma; cM[t] = mu; cR[t] = rs;
     }
-    a.db_part[(long)blockIdx.y * a.ld + col] = acc;
+    __syncthreads();
+    const int cg = t & 31, rl = t >> 5, c0 = blockIdx.x * 256 + cg * 8;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    if (c0 < a.ld) {
+        const T* dy = (const T*)a.dy;
+        const T* h = (const T*)a.h;
+        T* dpre = (T*)a.dpre;
+        const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
+        for (int r = blockIdx.y * RB + rl; r < r1; r += 8) {
+            float hv[8], d[8], o[8];
+            load8<T>(h + (long)r * a.ld + c0, hv);
+            load8<T>(dy + (long)r * a.ld + c0, d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = cg * 8 + i;
+                const float xh = (hv[i] - cM[c]) * cR[c];
+                const float dh = cA[c] * (a.count * d[i] - cB[c] - xh * cG[c]);
+                o[i] = dh * (-expm1f(-hv[i]));
+                acc[i] += o[i];
+            }
+            store8<T>(dpre + (long)r * a.ld + c0, o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[rl][cg * 8 + i] = acc[i];
+    __syncthreads();
+    const int col = blockIdx.x * 256 + t;
+    if (col < a.ld) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][t];
+        a.db_part[(long)blockIdx.y * a.ld + col] = s;
+    }
 }
 
 // =========================================================================================
 // loss head: logits = f W6 + b6 ; labeled / unlabeled / fake losses of mr_gan.py:146-149 ; train error
 // :161 ; closed-form dlogits ; dW6, db6 ; and dL/d(pre5) = (dlogits W6^T) * [f > 0].
 // One block = 64 rows of one segment.  LDS: f tile as fp32 [64][feat+4], W6 [feat][8], dlogits [64][8].
+// Per-block partial gradients go to part[blk][...]; reduce_partials_kernel folds them to <= 8 slabs.
 // =========================================================================================
 constexpr int HR = HEAD_ROWS;
 template <typename T>
@@ -124,14 +213,20 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     const int blk = seg * gridDim.x + blockIdx.x;
     const T* f = (const T*)a.f + (long)seg * a.f_bs;
 
-    for (int i = t; i < HR * a.feat; i += 256) {
-        const int r = i / a.feat, c = i - r * a.feat;
-        const int row = row_blk + r;
-        f_lds[r * LDF + c] = (row < a.rows) ? Elem<T>::to_f32(f[(long)row * a.ldf + c]) : 0.f;
+    const int cpr = a.feat / 8;                // 8-element chunks per row
+    for (int ci = t; ci < HR * cpr; ci += 256) {
+        const int r = ci / cpr, c = (ci - r * cpr) * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (row_blk + r < a.rows) load8<T>(f + (long)(row_blk + r) * a.ldf + c, v);
+        *(f32x4*)(f_lds + r * LDF + c) = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)(f_lds + r * LDF + c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     }
-    for (int i = t; i < a.feat * KMAX; i += 256) {
-        const int k = i / KMAX, c = i - k * KMAX;
-        w_lds[i] = (c < a.classes && k < a.feat_valid) ? a.w[(long)k * a.ldw + c] : 0.f;
+    for (int k = t; k < a.feat; k += 256) {
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+        if (k < a.feat_valid) { w0 = *(const f32x4*)(a.w + (long)k * a.ldw); w1 = *(const f32x4*)(a.w + (long)k * a.ldw + 4); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { if (c >= a.classes) w0[c] = 0.f; if (c + 4 >= a.classes) w1[c] = 0.f; }
+        *(f32x4*)(w_lds + k * KMAX) = w0; *(f32x4*)(w_lds + k * KMAX + 4) = w1;
     }
     __syncthreads();
 
@@ -143,8 +238,9 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     for (int kk = 0; kk < a.feat / 4; ++kk) {
         const int k = kk * 4 + part;
         const float fv = f_lds[r * LDF + k];
+        const f32x4 w0 = *(const f32x4*)(w_lds + k * KMAX), w1 = *(const f32x4*)(w_lds + k * KMAX + 4);
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) l[c] = fmaf(fv, w_lds[k * KMAX + c], l[c]);
+        for (int c = 0; c < 4; ++c) { l[c] = fmaf(fv, w0[c], l[c]); l[4 + c] = fmaf(fv, w1[c], l[4 + c]); }
     }
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
@@ -195,10 +291,12 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
         }
     }
     if (part == 0) {
+        *(f32x4*)(dl_lds + r * KMAX) = (f32x4){dl[0], dl[1], dl[2], dl[3]};
+        *(f32x4*)(dl_lds + r * KMAX + 4) = (f32x4){dl[4], dl[5], dl[6], dl[7]};
+        if (a.logits && rowvalid) {
+            float* lp = a.logits + (long)seg * a.logits_bs + (long)row * KMAX;
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) {
-            dl_lds[r * KMAX + c] = dl[c];
-            if (a.logits && rowvalid) a.logits[(long)seg * a.logits_bs + (long)row * KMAX + c] = (c < a.classes) ? l[c] : 0.f;
+            for (int c = 0; c < KMAX; ++c) lp[c] = (c < a.classes) ? l[c] : 0.f;
         }
     } else { loss0 = 0.f; loss1 = 0.f; err = 0.f; }
     loss0 = wave_sum(loss0); loss1 = wave_sum(loss1); err = wave_sum(err);
@@ -216,10 +314,11 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     if (kind == HEAD_EVAL || kind == HEAD_LOGITS) return;
 
     // ---- backward of the last dense: thread <-> feature column j ----
+    float* part_row = a.part + (long)blk * a.part_stride;
     if (t < KMAX) {
         float s = 0.f;
         for (int rr = 0; rr < HR; ++rr) s += dl_lds[rr * KMAX + t];
-        a.db_part[blk * KMAX + t] = s;
+        part_row[a.off_db + t] = s;
     }
     for (int j = t; j < a.feat; j += 256) {
         float wj[KMAX], dw[KMAX];
@@ -229,21 +328,35 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
         T* dpre = (T*)a.dpre + (long)seg * a.dpre_bs;
         for (int rr = 0; rr < HR; ++rr) {
             const float fv = f_lds[rr * LDF + j];
+            const f32x4 d0 = *(const f32x4*)(dl_lds + rr * KMAX), d1 = *(const f32x4*)(dl_lds + rr * KMAX + 4);
             float dfe = 0.f;
 #pragma unroll
-            for (int c = 0; c < KMAX; ++c) {
-                const float d = dl_lds[rr * KMAX + c];
-                dfe = fmaf(d, wj[c], dfe);
-                dw[c] = fmaf(fv, d, dw[c]);
+            for (int c = 0; c < 4; ++c) {
+                dfe = fmaf(d0[c], wj[c], dfe); dfe = fmaf(d1[c], wj[4 + c], dfe);
+                dw[c] = fmaf(fv, d0[c], dw[c]); dw[4 + c] = fmaf(fv, d1[c], dw[4 + c]);
             }
             const float dp = (fv > 0.f) ? dfe : 0.f;
             if (row_blk + rr < a.rows) dpre[(long)(row_blk + rr) * a.ldd + j] = Elem<T>::from_f32(dp);
             dbf += dp;
         }
-#pragma unroll
-        for (int c = 0; c < KMAX; ++c) a.dw_part[((long)blk * a.feat + j) * KMAX + c] = dw[c];
-        a.dbf_part[(long)blk * a.ldbf + j] = dbf;
+        *(f32x4*)(part_row + (long)j * KMAX) = (f32x4){dw[0], dw[1], dw[2], dw[3]};
+        *(f32x4*)(part_row + (long)j * KMAX + 4) = (f32x4){dw[4], dw[5], dw[6], dw[7]};
+        part_row[a.off_dbf + j] = dbf;
     }
+}
+
+// dst[g][i] = sum of src[p][i] over the partial rows p of group g (p = g, g + ngroups, ...)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* src, int nsrc, long stride, int n, int ngroups, float* dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = g;
+    for (; p + 3 * ngroups < nsrc; p += 4 * ngroups) {
+        s0 += src[(long)p * stride + i]; s1 += src[(long)(p + ngroups) * stride + i];
+        s2 += src[(long)(p + 2 * ngroups) * stride + i]; s3 += src[(long)(p + 3 * ngroups) * stride + i];
+    }
+    for (; p < nsrc; p += ngroups) s0 += src[(long)p * stride + i];
+    dst[(long)g * stride + i] = (s0 + s1) + (s2 + s3);
 }
 
 // =========================================================================================
@@ -252,32 +365,41 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
 // =========================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
+    __shared__ float gj_lds[256];
     __shared__ float red[4];
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int t = threadIdx.x;
     float diff = 0.f;
-    if (j < a.feat_valid) {
-        float sf = 0.f, sr = 0.f;
-        for (int p = 0; p < a.npart_fake; ++p) sf += a.cs[(long)p * a.ldcs + j];
-        for (int p = 0; p < a.npart_real; ++p) sr += a.cs[(long)(a.npart_fake + p) * a.ldcs + j];
-        diff = (sf - sr) / a.count;
+    if (t < a.feat_valid) {
+        float sf0 = 0.f, sf1 = 0.f, sr0 = 0.f, sr1 = 0.f;
+        int p = 0;
+        for (; p + 1 < a.npart_fake; p += 2) { sf0 += a.cs[(long)p * a.ldcs + t]; sf1 += a.cs[(long)(p + 1) * a.ldcs + t]; }
+        for (; p < a.npart_fake; ++p) sf0 += a.cs[(long)p * a.ldcs + t];
+        const float* csr = a.cs + (long)a.npart_fake * a.ldcs;
+        for (p = 0; p + 1 < a.npart_real; p += 2) { sr0 += csr[(long)p * a.ldcs + t]; sr1 += csr[(long)(p + 1) * a.ldcs + t]; }
+        for (; p < a.npart_real; ++p) sr0 += csr[(long)p * a.ldcs + t];
+        diff = ((sf0 + sf1) - (sr0 + sr1)) / a.count;
     }
-    if (blockIdx.y == 0 && gridDim.x == 1) {
-        float s = wave_sum(diff * diff);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float loss = (red[0] + red[1] + red[2] + red[3]) / (float)a.feat_valid;
-            if (a.loss_out) *a.loss_out = loss;
-            if (a.accum) *a.accum += loss;
-        }
+    gj_lds[t] = a.grad_scale * 2.0f / ((float)a.feat_valid * a.count) * diff;
+    if (blockIdx.y == 0) {
+        const float s = wave_sum(diff * diff);
+        if ((t & 63) == 0) red[t >> 6] = s;
     }
-    if (j >= a.feat) return;
-    const float gj = 2.0f / ((float)a.feat_valid * a.count) * diff;
+    __syncthreads();
+    if (blockIdx.y == 0 && t == 0) {
+        const float loss = (red[0] + red[1] + red[2] + red[3]) / (float)a.feat_valid;
+        if (a.loss_out) *a.loss_out = loss;
+        if (a.accum) *a.accum += loss;
+    }
+    const int cg = t & 31, rl = t >> 5, c0 = cg * 8;
+    if (c0 >= a.feat) return;
     T* dpre = (T*)a.dpre;
-    const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.rows, r0 + a.rows_per_block);
-    for (int r = r0; r < r1; ++r) {
-        const uint32_t w = a.mask[(long)r * a.ldm + (j >> 5)];
-        dpre[(long)r * a.ldd + j] = Elem<T>::from_f32(((w >> (j & 31)) & 1u) ? gj : 0.f);
+    const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
+    for (int r = blockIdx.y * RB + rl; r < r1; r += 8) {
+        const uint32_t w = a.mask[(long)r * a.ldm + (c0 >> 5)] >> (c0 & 31);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ((w >> i) & 1u) ? gj_lds[c0 + i] : 0.f;
+        store8<T>(dpre + (long)r * a.ldd + c0, v);
     }
 }
 
@@ -294,37 +416,68 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part,
 // One block = one 64x64 tile of one tensor.  The gradient is the sum of `nslab` fp32 slabs (split-K
 // weight-gradient slabs, per-row-tile bias partial sums), so no separate reduction pass exists on
 // one GPU.  Also refreshes the bf16 weight copies W[K][N] and W^T[N][K] the bf16 GEMMs read.
+// Small tiles (<= 64 four-element groups: biases, BN affine) spread their slabs over the otherwise
+// idle threads ("slab lanes") and combine through LDS.
 // =========================================================================================
+__device__ __forceinline__ f32x4 adam_sum_slabs(const float* g, long stride, int first, int step, int nslab) {
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+    int sl = first;
+    for (; sl + 3 * step < nslab; sl += 4 * step) {
+        g0 += *(const f32x4*)(g + (long)sl * stride);
+        g1 += *(const f32x4*)(g + (long)(sl + step) * stride);
+        g2 += *(const f32x4*)(g + (long)(sl + 2 * step) * stride);
+        g3 += *(const f32x4*)(g + (long)(sl + 3 * step) * stride);
+    }
+    for (; sl < nslab; sl += step) g0 += *(const f32x4*)(g + (long)sl * stride);
+    return (g0 + g1) + (g2 + g3);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     __shared__ float tl[64 * 65];
     const int t = threadIdx.x;
     if (blockIdx.x < a.ntiles) {
     const AdamTile tile = a.tiles[blockIdx.x];
-    const int tr = t >> 4, tc = (t & 15) * 4;
     const float lr_t = a.st->lr_t;
+    const int qpr = tile.cols >> 2;                       // four-element groups per row
+    const int nq = tile.rows * qpr;
+    const bool small = nq <= 64 && !tile.wt16;            // slab-parallel mode
+    const int lanes = small ? 4 : 1;
+#pragma unroll 1
+    for (int u = 0; u < (small ? 1 : 4); ++u) {
+        int r, tc, sl0 = 0;
+        if (small) { const int qi = t & 63; sl0 = t >> 6; r = qi / qpr; tc = (qi - r * qpr) * 4; if (qi >= nq) r = tile.rows; }
+        else { r = (t >> 4) + 16 * u; tc = (t & 15) * 4; }
+        const bool valid = r < tile.rows && tc < tile.cols;
+        const long off = (long)r * tile.ld + tc;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f}, pn = g;
+        if (valid) {
+            if (a.mode == ADAM_FROM_FLAT) { if (sl0 == 0) g = *(const f32x4*)(tile.flat + off); }
+            else g = adam_sum_slabs(tile.g + off, tile.slab_stride, sl0, lanes, tile.nslab);
+        }
+        if (small) {                                      // combine the slab lanes
+            *(f32x4*)(tl + t * 4) = g;
+            __syncthreads();
+            if (sl0 == 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int r = tr + 16 * u;
-        f32x4 pn = {0.f, 0.f, 0.f, 0.f};
-        if (r < tile.rows && tc < tile.cols) {
-            const long off = (long)r * tile.ld + tc;
-            f32x4 g = {0.f, 0.f, 0.f, 0.f};
-            if (a.mode == ADAM_FROM_FLAT) g = *(const f32x4*)(tile.flat + off);
-            else
-                for (int s = 0; s < tile.nslab; ++s) g += *(const f32x4*)(tile.g + (long)s * tile.slab_stride + off);
-            if (a.mode == ADAM_REDUCE_ONLY) { *(f32x4*)(tile.flat + off) = g; continue; }
-            f32x4 m = *(const f32x4*)(tile.m + off), v = *(const f32x4*)(tile.v + off);
-            pn = *(const f32x4*)(tile.p + off);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                m[i] = a.b1 * m[i] + (1.0f - a.b1) * g[i];
-                v[i] = a.b2 * v[i] + (1.0f - a.b2) * g[i] * g[i];
-                pn[i] = pn[i] - lr_t * m[i] / (sqrtf(v[i]) + a.eps);
+                for (int k = 1; k < 4; ++k) g += *(const f32x4*)(tl + (t + 64 * k) * 4);
             }
-            *(f32x4*)(tile.m + off) = m; *(f32x4*)(tile.v + off) = v; *(f32x4*)(tile.p + off) = pn;
-            if (tile.w16) {
-                bf16x4 w = {(__bf16)pn[0], (__bf16)pn[1], (__bf16)pn[2], (__bf16)pn[3]};
-                *(bf16x4*)(tile.w16 + off) = w;
+        }
+        if (valid && sl0 == 0) {
+            if (a.mode == ADAM_REDUCE_ONLY) *(f32x4*)(tile.flat + off) = g;
+            else {
+                f32x4 m = *(const f32x4*)(tile.m + off), v = *(const f32x4*)(tile.v + off);
+                pn = *(const f32x4*)(tile.p + off);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    m[i] = a.b1 * m[i] + (1.0f - a.b1) * g[i];
+                    v[i] = a.b2 * v[i] + (1.0f - a.b2) * g[i] * g[i];
+                    pn[i] = pn[i] - lr_t * m[i] / (sqrtf(v[i]) + a.eps);
+                }
+                *(f32x4*)(tile.m + off) = m; *(f32x4*)(tile.v + off) = v; *(f32x4*)(tile.p + off) = pn;
+                if (tile.w16) {
+                    bf16x4 w = {(__bf16)pn[0], (__bf16)pn[1], (__bf16)pn[2], (__bf16)pn[3]};
+                    *(bf16x4*)(tile.w16 + off) = w;
+                }
             }
         }
         if (tile.wt16) {
@@ -345,16 +498,27 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     }
     }
     // ---- metrics: the extra last block folds this sub-step's loss partials ----
-    if (blockIdx.x == a.ntiles && t == 0 && a.step_out) {
+    if (blockIdx.x == a.ntiles && a.step_out) {
+        __shared__ float ms[3][256];
         float s[3] = {0.f, 0.f, 0.f};
-        if (a.mode == ADAM_FROM_FLAT) { for (int i = 0; i < 3; ++i) s[i] = a.flat_tail[i]; }
+        if (a.mode == ADAM_FROM_FLAT) { if (t == 0) for (int i = 0; i < 3; ++i) s[i] = a.flat_tail[i]; }
         else {
-            for (int b = 0; b < a.nloss_part; ++b)
+            for (int b = t; b < a.nloss_part; b += 256)
                 for (int i = 0; i < 3; ++i) s[i] += a.loss_part[b * 4 + i];
-            for (int i = 0; i < 3; ++i) s[i] *= a.inv_rows;
+            for (int i = 0; i < 3; ++i) ms[i][t] = s[i];
+            __syncthreads();
+            if (t == 0) {
+                for (int i = 0; i < 3; ++i) {
+                    float acc = 0.f;
+                    for (int k = 0; k < 256; ++k) acc += ms[i][k];       // fixed order: reproducible
+                    s[i] = acc * a.inv_rows;
+                }
+            }
         }
-        if (a.mode == ADAM_REDUCE_ONLY) { for (int i = 0; i < 3; ++i) a.flat_tail[i] = s[i]; a.flat_tail[3] = 0.f; }
-        else { for (int i = 0; i < 3; ++i) { a.step_out[i] = s[i]; a.accum[i] += s[i]; } }
+        if (t == 0) {
+            if (a.mode == ADAM_REDUCE_ONLY) { for (int i = 0; i < 3; ++i) a.flat_tail[i] = s[i]; a.flat_tail[3] = 0.f; }
+            else { for (int i = 0; i < 3; ++i) { a.step_out[i] = s[i]; a.accum[i] += s[i]; } }
+        }
     }
 }
 
@@ -364,7 +528,7 @@ __global__ void noise_debug_kernel(uint64_t seed, uint32_t site, uint32_t seg, u
     const int r4 = blockIdx.y * 4;
     if (col >= cols) return;
     float n[4];
-    normal4(seed, site * 256u + seg, step, (row0 + (uint32_t)r4) >> 2, (uint32_t)col, n);
+    normal4(noise_key(seed, site * 256u + seg, step), (row0 + (uint32_t)r4) >> 2, (uint32_t)col, n);
     for (int j = 0; j < 4; ++j) if (r4 + j < rows) out[(long)(r4 + j) * cols + col] = n[j];
 }
 
@@ -386,13 +550,15 @@ int launch_stage(int bf16, const StageArgs& a, hipStream_t s) {
 }
 
 int launch_bn_apply(int bf16, const BnApplyArgs& a, hipStream_t s) {
-    dim3 grid(ceil_div(a.ld, 256), ceil_div(a.rows, 32));
+    dim3 grid(ceil_div(a.ld, 256), ceil_div(a.rows, RB));
     LAUNCH_T(bn_apply_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }
 
+int stat_row_blocks(int rows) { return ceil_div(rows, RB); }
+
 int launch_bn_bwd(int bf16, const BnBwdArgs& a, hipStream_t s) {
-    dim3 grid(ceil_div(a.ld, 256), ceil_div(a.rows, a.rows_per_block));
+    dim3 grid(ceil_div(a.ld, 256), ceil_div(a.rows, RB));
     LAUNCH_T(bn_bwd_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }
@@ -406,16 +572,21 @@ int init_kernel_attributes() {
 }
 
 int launch_head(int bf16, const HeadArgs& a, hipStream_t s) {
-    if (a.feat > 256 || (a.feat % 4) != 0 || a.classes > KMAX) return -3;
+    if (a.feat > 256 || (a.feat % 8) != 0 || a.classes > KMAX) return -3;
     const size_t smem = sizeof(float) * ((size_t)HR * (a.feat + 4) + (size_t)a.feat * KMAX + HR * KMAX + 16);
     dim3 grid(ceil_div(a.rows, HR), a.nseg);
     LAUNCH_T(head_kernel, grid, dim3(256), smem, s, a);
     RET_LAUNCH;
 }
 
+int launch_reduce_partials(const float* src, int nsrc, long stride, int n, int ngroups, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 256), ngroups), dim3(256), 0, s, src, nsrc, stride, n, ngroups, dst);
+    RET_LAUNCH;
+}
+
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s) {
-    if (a.feat > 256) return -3;
-    dim3 grid(1, ceil_div(a.rows, a.rows_per_block));
+    if (a.feat > 256 || (a.feat % 8) != 0) return -3;
+    dim3 grid(1, ceil_div(a.rows, RB));
     LAUNCH_T(fm_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }

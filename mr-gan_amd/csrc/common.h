@@ -45,34 +45,34 @@ template <> struct Elem<__bf16> {
 };
 
 // ---------------------------------------------------------------------------------------
-// Philox4x32-10 + Box-Muller.  Restated bit-for-bit in oracle/mrgan_oracle.py (device_normal).
-// counter = (col, row>>2, site*256+seg, sub-step), key = seed; the four outputs are the normals of
-// rows 4q..4q+3 at that column.
+// Layer-noise / z generator: a counter hash + Box-Muller.  Restated bit-for-bit in
+// oracle/mrgan_oracle.py (device_normal).  One call yields the four normals of rows 4q..4q+3 at one
+// column of one noise site in one sub-step:
+//     key = mix(seed, site*256+seg, sub-step)                       (wave-uniform)
+//     a   = mix32(key ^ q*0x9E3779B1)                               (per row group)
+//     x0  = mix32(a ^ col*0x85EBCA77),  x1 = mix32(rotl16(a) + col*0xC2B2AE3D + 1)
+// and the four 16-bit halves of (x0, x1) are the uniforms of two Box-Muller pairs.  mix32 is the
+// "lowbias32" integer finaliser; ~5 VALU ops per normal for the bits (Philox4x32-10: ~25), which
+// matters because the forward GEMM epilogues draw one normal per output element.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
-                                              uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
 }
-
-__device__ __forceinline__ float u01(uint32_t x) {
-    return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);     // exact in fp32, inside (0,1)
+__device__ __forceinline__ uint32_t noise_key(uint64_t seed, uint32_t site_seg, uint32_t step) {
+    return mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) ^ mix32(step ^ mix32(site_seg))));
 }
+__device__ __forceinline__ float u16_01(uint32_t v) { return ((float)v + 0.5f) * (1.0f / 65536.0f); }   // inside (0,1)
 
 // n[0..3]: standard normals for rows 4q..4q+3 at column col
-__device__ __forceinline__ void normal4(uint64_t seed, uint32_t site_seg, uint32_t step, uint32_t q,
-                                        uint32_t col, float n[4]) {
-    uint32_t c0 = col, c1 = q, c2 = site_seg, c3 = step;
-    philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+__device__ __forceinline__ void normal4(uint32_t key, uint32_t q, uint32_t col, float n[4]) {
+    const uint32_t a = mix32(key ^ (q * 0x9E3779B1u));
+    const uint32_t x0 = mix32(a ^ (col * 0x85EBCA77u));
+    const uint32_t x1 = mix32(((a << 16) | (a >> 16)) + col * 0xC2B2AE3Du + 1u);
     // r = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u); v_sin/v_cos take revolutions
-    const float r0 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c0)));
-    const float r1 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c2)));
-    const float t0 = u01(c1), t1 = u01(c3);
+    const float r0 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u16_01(x0 & 0xFFFFu)));
+    const float r1 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u16_01(x1 & 0xFFFFu)));
+    const float t0 = u16_01(x0 >> 16), t1 = u16_01(x1 >> 16);
     n[0] = r0 * __builtin_amdgcn_cosf(t0);
     n[1] = r0 * __builtin_amdgcn_sinf(t0);
     n[2] = r1 * __builtin_amdgcn_cosf(t1);

@@ -22,6 +22,7 @@ int launch_tr_probe(unsigned short* out, hipStream_t s);
 namespace {
 
 thread_local std::string g_err;
+int g_ablate = 0;     // timing experiments (mrgan_debug_ablate)
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -79,6 +80,7 @@ struct mrgan_handle {
     bool bf16, sync_stats, flat_grads, own_ws;
     int es;                               // activation element size
     int B, S, tiles_m, Bg;                // local batch, segment stride, row tiles per segment, global batch
+    float stat_count, fm_scale;           // rows behind a batch statistic; 1/world when statistics stay per-shard
     int Dp, nzp, Fp, F;                   // padded input / z / feature widths
     char* ws; size_t ws_bytes;
 
@@ -102,8 +104,8 @@ struct mrgan_handle {
     float *bn_mu, *bn_rstd;
     // partial sums
     float *cs_bn1, *cs_bn2, *cs_db[4], *cs_f, *cs_db3g, *cs_db2g, *cs_dbeta, *cs_dgamma, *db1g_part;
-    float *dw6_part, *db6_part, *dbf_part, *loss_part;
-    int nblk_head, bnb_rows_per_block, bnb_blocks;
+    float *head_part, *head_red, *loss_part; int head_stride, head_groups;
+    int nblk_head, bnb_blocks;
     AdamTile *tiles_g_dev, *tiles_d_dev; int ntiles_g, ntiles_d;
 
     // per-launch hipEvent profiling (bench.py's live roofline measurement)
@@ -161,11 +163,12 @@ inline dim3 grid2d(int prow, int pcol) { return dim3(ceil_div(pcol, 64), ceil_di
 // ------------------------------------------------------------------------------------------------
 int pad64(int x) { return (int)round_up(x, PADW); }
 
-int choose_splits(int Kp, int Np, int nseg, int rows) {
-    const int tiles = ceil_div(Kp, 128) * ceil_div(Np, 128) * nseg;
-    int s = 320 / tiles;                       // aim for ~1-1.25 waves of 256 CUs
-    s = std::min(s, ceil_div(rows, 256));       // keep >= 256 reduction rows per split
-    return std::max(1, std::min(s, 16));
+constexpr int MAX_SLABS = 16;
+int choose_splits(int Kp, int Np, int vrows) {
+    const int tiles = ceil_div(Kp, 128) * ceil_div(Np, 128);
+    int s = 256 / tiles;                        // ~one block per CU for the big layers
+    s = std::min(s, ceil_div(vrows, 512));      // keep >= 512 reduction rows per slab
+    return std::max(1, std::min(s, MAX_SLABS));
 }
 
 int validate(const mrgan_config& c) {
@@ -190,6 +193,8 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->flat_grads = (c.flags & MRGAN_FLAG_FLAT_GRADS) != 0;
     h->B = c.batch; h->S = (int)round_up(c.batch, SEG_ALIGN); h->tiles_m = ceil_div(c.batch, 128);
     h->Bg = c.batch * c.world;
+    h->stat_count = (float)(h->sync_stats ? h->Bg : h->B);
+    h->fm_scale = h->sync_stats ? 1.0f : 1.0f / (float)c.world;
     h->Dp = pad64(c.d_in); h->nzp = pad64(c.noise_size);
     h->F = c.d_hidden[4]; h->Fp = pad64(h->F);
     const int B = h->B, S = h->S, tm = h->tiles_m;
@@ -268,32 +273,33 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->cs_db3g = a.take<float>((size_t)tm * h->Dp);
     h->cs_db2g = a.take<float>((size_t)tm * h->g[1].Np);
     h->cs_dbeta = a.take<float>((size_t)tm * N1p); h->cs_dgamma = a.take<float>((size_t)tm * N1p);
-    h->bnb_rows_per_block = 32; h->bnb_blocks = ceil_div(B, 32);
+    h->bnb_blocks = stat_row_blocks(B);
     h->db1g_part = a.take<float>((size_t)h->bnb_blocks * N1p);
     h->nblk_head = 3 * ceil_div(B, HEAD_ROWS);
-    h->dw6_part = a.take<float>((size_t)h->nblk_head * h->Fp * KMAX);
-    h->db6_part = a.take<float>((size_t)h->nblk_head * KMAX);
-    h->dbf_part = a.take<float>((size_t)h->nblk_head * h->Fp);
+    h->head_stride = (int)round_up(h->Fp * KMAX + KMAX + h->Fp, 64);      // dW6 | db6 | bias grad of the feature layer
+    h->head_groups = std::min(8, h->nblk_head);
+    h->head_part = a.take<float>((size_t)h->nblk_head * h->head_stride);
+    h->head_red = a.take<float>((size_t)h->head_groups * h->head_stride);
     h->loss_part = a.take<float>((size_t)h->nblk_head * 4);
 
     // ---- weight-gradient slabs ---------------------------------------------------------------------
     for (int l = 0; l < 5; ++l) {
         Dense& L = h->d[l];
-        L.splits = choose_splits(L.Kp, L.Np, 3, B);
-        L.slabs = a.take<float>((size_t)3 * L.splits * L.Kp * L.Np);
+        L.splits = choose_splits(L.Kp, L.Np, 2 * S + B);
+        L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     for (int l = 0; l < 3; ++l) {
         Dense& L = h->g[l];
-        L.splits = choose_splits(L.Kp, L.Np, 1, B);
+        L.splits = choose_splits(L.Kp, L.Np, B);
         L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     // ---- fused-mode gradient sources ----------------------------------------------------------------
     auto src = [&](Tensor& t, const float* g, int nslab, long stride) { t.g = g; t.nslab = nslab; t.slab_stride = stride; };
-    for (int l = 0; l < 5; ++l) src(*h->d[l].W, h->d[l].slabs, 3 * h->d[l].splits, (long)h->d[l].Kp * h->d[l].Np);
+    for (int l = 0; l < 5; ++l) src(*h->d[l].W, h->d[l].slabs, h->d[l].splits, (long)h->d[l].Kp * h->d[l].Np);
     for (int l = 0; l < 4; ++l) src(*h->d[l].b, h->cs_db[l], 3 * tm, h->d[l].Np);
-    src(*h->d[4].b, h->dbf_part, h->nblk_head, h->Fp);
-    src(*h->d[5].W, h->dw6_part, h->nblk_head, (long)h->Fp * KMAX);
-    src(*h->d[5].b, h->db6_part, h->nblk_head, KMAX);
+    src(*h->d[4].b, h->head_red + h->Fp * KMAX + KMAX, h->head_groups, h->head_stride);
+    src(*h->d[5].W, h->head_red, h->head_groups, h->head_stride);
+    src(*h->d[5].b, h->head_red + h->Fp * KMAX, h->head_groups, h->head_stride);
     for (int l = 0; l < 3; ++l) src(*h->g[l].W, h->g[l].slabs, h->g[l].splits, (long)h->g[l].Kp * h->g[l].Np);
     src(*h->g[0].b, h->db1g_part, h->bnb_blocks, N1p);
     src(h->gt[2], h->cs_dgamma, tm, N1p);
@@ -374,6 +380,7 @@ Epi base_epi(mrgan_handle* h) {
     e.seed = h->cfg.seed;
     e.row0 = (uint32_t)(h->cfg.rank * h->B);
     e.st = h->state + h->cur;
+    e.ablate = g_ablate;
     return e;
 }
 
@@ -383,6 +390,7 @@ int dense_fwd(mrgan_handle* h, const Dense& L, const void* x, int rows, int nb, 
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.M = rows; g.N = L.Np; g.K = L.Kp; g.nbatch = nb; g.splits = 1; g.kchunk = L.Kp; g.tiles_m = ceil_div(rows, 128);
+    g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
     g.A = x; g.a_bs = (long)h->S * L.Kp; g.a_si = L.Kp; g.a_sk = 1;
     if (h->bf16) { g.B = L.W->wt16; g.b_sj = L.Kp; g.b_sk = 1; }
     else { g.B = L.W->p; g.b_sk = L.Np; g.b_sj = 1; }
@@ -402,6 +410,7 @@ int dense_dx(mrgan_handle* h, const Dense& L, const void* dy, int rows, int nb, 
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.M = rows; g.N = L.Kp; g.K = L.Np; g.nbatch = nb; g.splits = 1; g.kchunk = L.Np; g.tiles_m = ceil_div(rows, 128);
+    g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
     g.A = dy; g.a_bs = (long)h->S * L.Np; g.a_si = L.Np; g.a_sk = 1;
     g.B = h->bf16 ? (const void*)L.W->w16 : (const void*)L.W->p; g.b_sk = 1; g.b_sj = L.Np;
     g.e = base_epi(h);
@@ -414,14 +423,17 @@ int dense_dx(mrgan_handle* h, const Dense& L, const void* dy, int rows, int nb, 
     return run_gemm(h, EPI_DX, g, s);
 }
 
-// dW slabs = X^T dY over `rows` rows of each of nb segments
-int dense_dw(mrgan_handle* h, const Dense& L, const void* x, const void* dy, int rows, int nb, hipStream_t s) {
+// dW slabs = X^T dY.  The nseg segments ([nseg][S] rows, `rows` valid in each) form ONE virtual reduction
+// range that is cut into L.splits slabs, so the Adam kernel sums at most MAX_SLABS slabs per tensor.
+int dense_dw(mrgan_handle* h, const Dense& L, const void* x, const void* dy, int rows, int nseg, hipStream_t s) {
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.M = L.Kp; g.N = L.Np; g.K = rows; g.nbatch = nb; g.splits = L.splits; g.tiles_m = ceil_div(L.Kp, 128);
-    g.kchunk = (int)round_up(ceil_div(rows, L.splits), 64);
-    g.A = x; g.a_bs = (long)h->S * L.Kp; g.a_si = 1; g.a_sk = L.Kp;
-    g.B = dy; g.b_bs = (long)h->S * L.Np; g.b_sk = L.Np; g.b_sj = 1;
+    const int vrows = (nseg - 1) * h->S + rows;
+    g.M = L.Kp; g.N = L.Np; g.K = vrows; g.nbatch = 1; g.splits = L.splits; g.tiles_m = ceil_div(L.Kp, 128);
+    g.kchunk = (int)round_up(ceil_div(vrows, L.splits), 64);
+    g.seg_stride = h->S; g.seg_rows = rows;
+    g.A = x; g.a_si = 1; g.a_sk = L.Kp;
+    g.B = dy; g.b_sk = L.Np; g.b_sj = 1;
     g.e = base_epi(h);
     g.e.ldo = L.Np; g.e.slab = L.slabs; g.e.slab_stride = (long)L.Kp * L.Np;
     return run_gemm(h, EPI_SLAB, g, s);
@@ -463,7 +475,7 @@ int gen_fwd_tail(mrgan_handle* h, int fake_seg_slot, uint32_t fake_seg_id, hipSt
     b.h = h->h1; b.out = h->hbn; b.ld = n; b.rows = h->B; b.cols = h->g[0].N;
     if (h->sync_stats) { b.cs1 = h->r_bn_stats; b.cs2 = h->r_bn_stats + n; b.npart = 1; }
     else { b.cs1 = h->cs_bn1; b.cs2 = h->cs_bn2; b.npart = h->tiles_m; }
-    b.ldcs = n; b.count = (float)h->Bg; b.eps = h->cfg.bn_eps;
+    b.ldcs = n; b.count = h->stat_count; b.eps = h->cfg.bn_eps;
     b.gamma = h->gt[2].p; b.beta = h->gt[3].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
     PROF(MRGAN_PROF_BN, launch_bn_apply(h->bf16, b, s));
     CHK(dense_fwd(h, h->g[1], h->hbn, h->B, 1, h->h2, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_NONE, nullptr, nullptr, true, s));
@@ -530,9 +542,11 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         hd.inv_count = 1.0f / (float)h->Bg; hd.unl_weight = h->cfg.unlabeled_weight;
         hd.logits = h->logits; hd.logits_bs = (long)h->S * KMAX;
         hd.dpre = h->dpre[4]; hd.dpre_bs = (long)h->S * h->Fp; hd.ldd = h->Fp;
-        hd.dw_part = h->dw6_part; hd.db_part = h->db6_part; hd.dbf_part = h->dbf_part; hd.ldbf = h->Fp;
+        hd.part = h->head_part; hd.part_stride = h->head_stride; hd.off_db = h->Fp * KMAX; hd.off_dbf = h->Fp * KMAX + KMAX;
         hd.loss_part = h->loss_part;
         PROF(MRGAN_PROF_HEAD, launch_head(h->bf16, hd, s));
+        PROF(MRGAN_PROF_HEAD, launch_reduce_partials(h->head_part, h->nblk_head, h->head_stride, h->head_stride, h->head_groups,
+                                                     h->head_red, s));
         for (int l = 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 3, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_SUM, h->cs_db[l - 1], nullptr, s));
@@ -569,8 +583,8 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         memset(&f, 0, sizeof f);
         if (h->sync_stats) { f.cs = h->r_fm; f.npart_fake = 1; f.npart_real = 1; }
         else { f.cs = h->cs_f; f.npart_fake = tm; f.npart_real = tm; }
-        f.ldcs = h->Fp; f.count = (float)h->Bg; f.feat = h->Fp; f.feat_valid = h->F;
-        f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B; f.rows_per_block = 32;
+        f.ldcs = h->Fp; f.count = h->stat_count; f.grad_scale = h->fm_scale; f.feat = h->Fp; f.feat_valid = h->F;
+        f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B;
         f.loss_out = h->step_out + 3; f.accum = h->accum + 3;
         PROF(MRGAN_PROF_FM, launch_fm(h->bf16, f, s));
         for (int l = 4; l >= 1; --l)
@@ -593,8 +607,8 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         b.dy = h->dhbn; b.h = h->h1; b.dpre = h->dpre1g; b.ld = N1p; b.rows = B; b.cols = h->g[0].N;
         if (h->sync_stats) { b.cs1 = h->r_bn_bwd; b.cs2 = h->r_bn_bwd + N1p; b.npart = 1; }
         else { b.cs1 = h->cs_dbeta; b.cs2 = h->cs_dgamma; b.npart = tm; }
-        b.ldcs = N1p; b.count = (float)h->Bg; b.gamma = h->gt[2].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
-        b.db_part = h->db1g_part; b.rows_per_block = h->bnb_rows_per_block;
+        b.ldcs = N1p; b.count = h->stat_count; b.gamma = h->gt[2].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
+        b.db_part = h->db1g_part;
         PROF(MRGAN_PROF_BN, launch_bn_bwd(h->bf16, b, s));
         CHK(dense_dw(h, h->g[2], h->h2, h->dxfake, B, 1, s));
         CHK(dense_dw(h, h->g[1], h->hbn, h->dpre2g, B, 1, s));
@@ -948,6 +962,8 @@ int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t ste
     return 0;
 }
 
+int mrgan_debug_ablate(int bits) { g_ablate = bits; return 0; }
+
 int mrgan_debug_tr_probe(uint16_t* out, mrgan_stream stream) {
     if (!out) return fail(-1, "null argument");
     CHK(launch_tr_probe(out, (hipStream_t)stream));
@@ -982,6 +998,7 @@ int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a, con
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.nbatch = 1; g.splits = 1; g.A = ta; g.B = tb;
+    g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
     g.e.st = st; g.e.out = to;
     int epi;
     if (op == 0) {

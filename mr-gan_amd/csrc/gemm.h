@@ -28,6 +28,7 @@ struct Epi {
     const float* bn_mu; const float* bn_rstd;   // CS_SUM_XHAT
     float* slab; long slab_stride;              // SLAB: fp32 [split][rows][ldo]
     const DevState* st;
+    int ablate;              // timing experiments only: 1 no noise, 2 no epilogue, 4 no main loop, 8 linear activation
 };
 
 struct GemmArgs {
@@ -35,20 +36,25 @@ struct GemmArgs {
     int nbatch, splits;      // grid.z = nbatch * splits ; splits > 1 only for SLAB
     int kchunk;              // reduction elements per split (multiple of the kernel's BK)
     int tiles_m;             // ceil(M / BM)
+    int seg_stride, seg_rows;  // SLAB: reduction index v is a row of [nseg][seg_stride] with only v % seg_stride < seg_rows valid
     const void* A; long a_bs, a_si, a_sk;   // A(i,k) at A + b*a_bs + i*a_si + k*a_sk
     const void* B; long b_bs, b_sk, b_sj;   // B(k,j) at B + b*b_bs + k*b_sk + j*b_sj
     Epi e;
 };
 
-// one wave's share of the block tile: MR x NR accumulators of 32x32
-template <typename T, int EPI, int MR, int NR, int WM>
+// one wave's share of the block tile: MR x NR accumulators of 32x32.
+// STAGED: the block's output tile is first assembled in LDS (`tile`, [BM][bn] of T, the dead staging
+// buffers) and then written with coalesced 16-byte stores -- the accumulator layout holds one column
+// per lane, so direct stores would be 2-byte pieces at a row stride (store-issue bound).
+template <typename T, int EPI, int MR, int NR, int WM, bool STAGED = false>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& g, int batch, int split,
                                          int tile_m, int row_blk, int col_blk, int wm, int wn, int lane,
-                                         float* lds /* >= 2*WM*(NR*32*WN) floats, free after main loop */,
-                                         int bn /* block tile width */) {
+                                         float* lds /* >= 2*WM*bn floats of scratch, disjoint from `tile` */,
+                                         int bn /* block tile width */, T* tile = nullptr) {
     const Epi& e = g.e;
     const int lc = lane & 31, lh = lane >> 5;
     const int M = g.M;
+    if (e.ablate & 2) { if (acc[0][0][0] == 12345.678f) ((float*)e.out)[0] = 1.f; return; }
 
     if constexpr (EPI == EPI_SLAB) {
         float* dst = e.slab + (long)(batch * g.splits + split) * e.slab_stride;
@@ -69,7 +75,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         uint32_t* mask = e.mask ? e.mask + (long)batch * e.mask_bs : nullptr;
         const T* hprev = e.h ? (const T*)e.h + (long)batch * e.h_bs : nullptr;
         const uint32_t step = e.st ? e.st->iter : 0u;
-        const uint32_t site_seg = e.site * 256u + e.seg0 + (uint32_t)batch;
+        const uint32_t nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)batch, step);
         float cs1[NR], cs2[NR];
 #pragma unroll
         for (int ni = 0; ni < NR; ++ni) { cs1[ni] = 0.f; cs2[ni] = 0.f; }
@@ -92,7 +98,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                     const int r4 = rbase + 8 * q;
                     float nz[4] = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (EPI == EPI_FWD) {
-                        if (e.sigma > 0.f) normal4(e.seed, site_seg, step, (e.row0 + (uint32_t)r4) >> 2, (uint32_t)col, nz);
+                        if (e.sigma > 0.f && !(e.ablate & 1)) normal4(nkey, (e.row0 + (uint32_t)r4) >> 2, (uint32_t)col, nz);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -102,7 +108,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                         if constexpr (EPI == EPI_FWD) {
                             v += bias;
                             if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
-                            else if (e.act == ACT_SOFTPLUS) v = softplus_f(v);
+                            else if (e.act == ACT_SOFTPLUS && !(e.ablate & 8)) v = softplus_f(v);
                             if (!colvalid) v = 0.f;
                             if (e.act == ACT_RELU && mask) {
                                 const unsigned long long bal = __ballot(v > 0.f);
@@ -117,7 +123,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                                 v = ((w >> (col & 31)) & 1u) ? v : 0.f;
                             } else if (e.act == ACT_SOFTPLUS) {
                                 const float hv = (rowvalid && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
-                                v *= -expm1f(-hv);            // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
+                                if (!(e.ablate & 8)) v *= -expm1f(-hv);   // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
                             }
                             if (!colvalid || !rowvalid) v = 0.f;
                             cs1[ni] += v;
@@ -126,9 +132,22 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                                 cs2[ni] += v * (h1 - mu) * rstd;
                             }
                         }
-                        if (rowvalid && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(v);
+                        if constexpr (STAGED) tile[(row - row_blk) * bn + (col - col_blk)] = Elem<T>::from_f32(v);
+                        else if (rowvalid && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(v);
                     }
                 }
+            }
+        }
+
+        if constexpr (STAGED) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+            constexpr int EPV = 16 / (int)sizeof(T);               // elements per 16-byte chunk
+            const int chunks_per_row = bn / EPV, bm = WM * MR * 32;
+            __syncthreads();
+            for (int cidx = threadIdx.x; cidx < bm * chunks_per_row; cidx += blockDim.x) {
+                const int r = cidx / chunks_per_row, c = cidx - r * chunks_per_row;
+                if (row_blk + r < M && col_blk + c * EPV < g.N)
+                    *(u32x4_t*)(out + (long)(row_blk + r) * e.ldo + col_blk + c * EPV) = *(const u32x4_t*)(tile + r * bn + c * EPV);
             }
         }
 

@@ -33,7 +33,7 @@ __device__ __forceinline__ int kc_off(int row, int chunk) {
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * KC_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[2 * KC_TILE_BYTES + 2048];   // + column-sum scratch
     char* As = lds;
     char* Bs = lds + KC_TILE_BYTES;
 
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
 
     const int lr = lane & 31, lh = lane >> 5;
     load_tile(0);
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
+    const int kc_end = (g.e.ablate & 4) ? 0 : g.K;
+    for (int k0 = 0; k0 < kc_end; k0 += BK) {
         __syncthreads();
         store_tile();
         __syncthreads();
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
         }
     }
     __syncthreads();
-    epilogue<__bf16, EPI, 2, 2, 2>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BN);
+    // the 128x128 bf16 output tile (32 KB) is assembled in the now-dead staging buffers
+    epilogue<__bf16, EPI, 2, 2, 2, true>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
+                                         (float*)(lds + 2 * KC_TILE_BYTES), BN, (__bf16*)lds);
 }
 
 // transposed fragment: 8 consecutive k (rows of the LDS image) for free index f0 + (lane&15)
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_kernel(const GemmArgs g) {
     const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
     const int row_blk = tile_m * BM, col_blk = tile_n * BN;
     const int k_begin = split * g.kchunk;
-    const int k_end = min(g.K, k_begin + g.kchunk);
+    const int k_end = (g.e.ablate & 4) ? k_begin : min(g.K, k_begin + g.kchunk);
 
     const __bf16* A = (const __bf16*)g.A + (long)batch * g.a_bs;
     const __bf16* B = (const __bf16*)g.B + (long)batch * g.b_bs;
@@ -136,11 +139,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_kernel(const GemmArgs g) {
 
     u32x4 ra[4], rb[4];
     auto load_tile = [&](int k0) {
+        const int kloc = k0 % g.seg_stride;             // BK divides seg_stride: a tile never straddles segments
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cidx = t + 256 * u, kr = cidx >> 4, c = cidx & 15;
             const u32x4 z = {0u, 0u, 0u, 0u};
-            const bool kok = (k0 + kr) < k_end;
+            const bool kok = (k0 + kr) < k_end && (kloc + kr) < g.seg_rows;
             ra[u] = (kok && row_blk + c * 8 < g.M) ? *(const u32x4*)(A + (long)(k0 + kr) * g.a_sk + row_blk + c * 8) : z;
             rb[u] = (kok && col_blk + c * 8 < g.N) ? *(const u32x4*)(B + (long)(k0 + kr) * g.b_sk + col_blk + c * 8) : z;
         }

@@ -47,10 +47,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 
     float ra[8], rb[8];
     auto load_tile = [&](int k0) {
+        const int kloc = (k0 % g.seg_stride) + sk;      // BK divides seg_stride: a tile never straddles segments
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + sk + j;
-            const bool kok = k < k_end;
+            const bool kok = k < k_end && (kloc + j) < g.seg_rows;
             ra[j] = (a_row_ok && kok) ? a_ptr[(long)k * g.a_sk] : 0.f;
             rb[j] = (b_col_ok && kok) ? b_ptr[(long)k * g.b_sk] : 0.f;
         }

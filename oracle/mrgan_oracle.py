@@ -14,7 +14,7 @@ only independent pins are (i) torch.autograd fp64 for every gradient
 
 Everything random is an explicit input (weights, z, layer noise), exactly as SURVEY 8c
 defines "identical seeds/inputs".  The noise generator restated at the bottom
-(Philox4x32-10 + Box-Muller) is the *build's* device generator, not the reference's
+(counter hash + Box-Muller) is the *build's* device generator, not the reference's
 MRG31k3p stream, which cannot be reproduced.
 """
 import numpy as np
@@ -333,36 +333,32 @@ def tiled_permutation(rng_perm, n_pool, n_total):
 
 
 # ----------------------------------------------------------------------------------------
-# The build's device noise generator, restated: Philox4x32-10 keyed by the seed, counter =
-# (column, row>>2, site*256+segment, sub-step); one call yields the four normals of rows
-# 4q..4q+3 at one column through two Box-Muller pairs.
+# The build's device noise generator, restated (mr-gan_amd/csrc/common.h: mix32 / noise_key / normal4):
+# a counter hash keyed by (seed, site*256+segment, sub-step); per (row>>2, column) it yields the four
+# normals of rows 4q..4q+3 at that column through two Box-Muller pairs on 16-bit uniforms.
 # ----------------------------------------------------------------------------------------
-_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
-_W0, _W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
 SITE_Z = 16     # generator input z; sites 0..4 are the GaussianNoise layers before dense 1..5
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3)]
-    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
-    k0 = np.uint32(k0)
-    k1 = np.uint32(k1)
-    m32 = np.uint64(0xFFFFFFFF)
+def mix32(x):
+    """'lowbias32' integer finaliser on uint32 arrays"""
+    x = np.asarray(x, dtype=np.uint32).copy()
     with np.errstate(over='ignore'):
-        for _ in range(10):
-            p0 = _M0 * c0.astype(np.uint64)
-            p1 = _M1 * c2.astype(np.uint64)
-            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & m32).astype(np.uint32)
-            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & m32).astype(np.uint32)
-            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
-            k0 = np.uint32(k0 + _W0)
-            k1 = np.uint32(k1 + _W1)
-    return c0, c1, c2, c3
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7feb352d)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846ca68b)
+        x ^= x >> np.uint32(16)
+    return x
 
 
-def _u01(x):
-    # ((x>>9)+0.5) * 2^-23 : exactly representable in fp32, strictly inside (0,1)
-    return ((x >> np.uint32(9)).astype(np.float64) + 0.5) * (1.0 / 8388608.0)
+def noise_key(seed, site_seg, step):
+    lo, hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    return mix32(lo ^ mix32(hi ^ mix32(np.uint32(step) ^ mix32(np.uint32(site_seg)))))
+
+
+def _u16_01(v):
+    return (v.astype(np.float64) + 0.5) * (1.0 / 65536.0)
 
 
 def device_normal(seed, site, seg, step, rows, cols, row0=0, dtype=np.float64):
@@ -371,14 +367,17 @@ def device_normal(seed, site, seg, step, rows, cols, row0=0, dtype=np.float64):
     segment (multiple of 4) -- used by data-parallel ranks."""
     assert row0 % 4 == 0
     nq = (rows + 3) // 4
+    key = noise_key(seed, site * 256 + seg, step)
     q = (np.arange(nq, dtype=np.uint32) + np.uint32(row0 // 4))[:, None]
     c = np.arange(cols, dtype=np.uint32)[None, :]
-    x0, x1, x2, x3 = philox4x32_10(c, q, np.uint32(site * 256 + seg), np.uint32(step),
-                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over='ignore'):
+        a = mix32(key ^ (q * np.uint32(0x9E3779B1)))
+        x0 = mix32(a ^ (c * np.uint32(0x85EBCA77)))
+        x1 = mix32(((a << np.uint32(16)) | (a >> np.uint32(16))) + c * np.uint32(0xC2B2AE3D) + np.uint32(1))
     out = np.empty((nq * 4, cols), dtype=np.float64)
-    for j, (a, b) in enumerate(((x0, x1), (x2, x3))):
-        r = np.sqrt(-2.0 * np.log(_u01(a)))
-        th = 2.0 * np.pi * _u01(b)
+    for j, x in enumerate((x0, x1)):
+        r = np.sqrt(-2.0 * np.log(_u16_01(x & np.uint32(0xFFFF))))
+        th = 2.0 * np.pi * _u16_01(x >> np.uint32(16))
         out[2 * j::4] = r * np.cos(th)
         out[2 * j + 1::4] = r * np.sin(th)
     return out[:rows].astype(dtype)

@@ -94,3 +94,8 @@ def frob_rel_err(a, ref):
     """Frobenius-relative error ||a - ref|| / ||ref||"""
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
     return float(np.linalg.norm(a - ref) / (np.linalg.norm(ref) + 1e-300))
+
+
+def cosine(a, ref):
+    a, ref = np.asarray(a, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    return float(a @ ref / (np.linalg.norm(a) * np.linalg.norm(ref) + 1e-300))

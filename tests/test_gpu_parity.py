@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import mrgan_oracle as O
-from tests.helpers import SEED, Case, frob_rel_err, rel_err, update_rel_err
+from tests.helpers import SEED, Case, cosine, frob_rel_err, rel_err, update_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -204,16 +204,17 @@ def test_bf16_gradients_track_oracle():
     _load(eng, case)
     da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]), _t(case.z1[0]))
     eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
-    # bf16 operands through up to 8 chained contractions: judged in the Frobenius norm
+    # bf16 operands through up to ten chained contractions: the gradient direction must be preserved
+    # (cosine similarity), its length within 10 %
     for i, (a, b) in enumerate(zip(eng.get_slot(E.NET_D, 2), gd)):
-        assert frob_rel_err(a, b) < 8e-2, ("dD", i, frob_rel_err(a, b))
+        assert cosine(a, b) > 0.995 and frob_rel_err(a, b) < 0.1, ("dD", i, cosine(a, b), frob_rel_err(a, b))
     orc.adam.apply(orc.d, gd, 'd')
     eng.disc_step(da, E.D_ADAM, E.D_ADAM)
     _, gg, _ = orc.gen_grads(**case.gen_inputs(0, 1))
     ga = E.Engine.gen_args(_t(case.x_unl2[0]), _t(case.z2[0]))
     eng.gen_step(ga, E.G_GEN, E.G_TAIL, want_outputs=False)
     for i, (a, b) in enumerate(zip(eng.get_slot(E.NET_G, 2), gg)):
-        assert frob_rel_err(a, b) < 1.2e-1, ("dG", i, frob_rel_err(a, b))
+        assert cosine(a, b) > 0.98 and frob_rel_err(a, b) < 0.2, ("dG", i, cosine(a, b), frob_rel_err(a, b))
     eng.close()
 
 

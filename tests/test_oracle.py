@@ -134,20 +134,28 @@ def test_tiled_permutation_tail_quirk():
     assert sorted(inds[5760:]) == list(range(240))      # tail touches only the first 240 pool rows
 
 
-def test_philox_known_answer():
-    # Random123 known-answer vectors for philox4x32-10
-    out = O.philox4x32_10(0, 0, 0, 0, 0, 0)
-    assert [int(x) for x in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    ff = 0xFFFFFFFF
-    out = O.philox4x32_10(ff, ff, ff, ff, ff, ff)
-    assert [int(x) for x in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    out = O.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
-    assert [int(x) for x in out] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+def test_noise_hash_properties():
+    # mix32 is a bijection with good avalanche: flipping one input bit flips ~half the output bits
+    x = np.arange(1 << 16, dtype=np.uint32) * np.uint32(2654435761)
+    h = O.mix32(x)
+    assert len(np.unique(h)) == len(h)
+    for bit in (0, 7, 31):
+        d = h ^ O.mix32(x ^ np.uint32(1 << bit))
+        pop = np.unpackbits(d.view(np.uint8)).mean() * 32
+        assert 15.0 < pop < 17.0
+    # distinct sites / steps / segments give unrelated streams
+    a = O.device_normal(1, 0, 0, 0, 64, 64)
+    for other in (O.device_normal(1, 1, 0, 0, 64, 64), O.device_normal(1, 0, 1, 0, 64, 64), O.device_normal(1, 0, 0, 1, 64, 64),
+                  O.device_normal(2, 0, 0, 0, 64, 64)):
+        assert abs(np.corrcoef(a.ravel(), other.ravel())[0, 1]) < 0.06
 
 
 def test_device_normal_moments():
     n = O.device_normal(seed=1234, site=1, seg=2, step=7, rows=2048, cols=256)
     assert abs(n.mean()) < 0.01 and abs(n.std() - 1.0) < 0.01
+    assert abs((n ** 4).mean() - 3.0) < 0.05                      # Gaussian kurtosis
+    assert abs(np.corrcoef(n[:-1].ravel(), n[1:].ravel())[0, 1]) < 0.01     # neighbouring rows
+    assert abs(np.corrcoef(n[:, :-1].ravel(), n[:, 1:].ravel())[0, 1]) < 0.01   # neighbouring columns
     # row-offset consistency (data-parallel shards draw the same global stream)
     n2 = O.device_normal(seed=1234, site=1, seg=2, step=7, rows=1024, cols=256, row0=1024)
     np.testing.assert_array_equal(n[1024:], n2)
