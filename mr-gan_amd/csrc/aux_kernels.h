@@ -70,7 +70,7 @@ int init_kernel_attributes();
 struct FmArgs {
     const float* cs; int npart_fake, npart_real, ldcs;   // column partial sums of f: fake rows first, then real
     float count, grad_scale; int feat, feat_valid;        // rows behind each mean; 1/world for per-shard statistics
-    const uint32_t* mask; int ldm;                        // relu mask of the fake rows' feature layer
+    const uint16_t* mask; int ldm;                        // lane-native relu mask (gemm.h) of the fake rows' feature layer
     void* dpre; int ldd; int rows;
     float* loss_out; float* accum;                        // step scalar + epoch accumulator (block 0 only)
 };

@@ -395,10 +395,12 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
     T* dpre = (T*)a.dpre;
     const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
     for (int r = blockIdx.y * RB + rl; r < r1; r += 8) {
-        const uint32_t w = a.mask[(long)r * a.ldm + (c0 >> 5)] >> (c0 & 31);
+        // lane-native mask layout (gemm.h): per (32-row block, column) two u16 words, one per lane half
+        const int rr = r & 31, half = (rr >> 2) & 1, bit = (rr & 3) | ((rr >> 3) << 2);
+        const uint32_t* mp = (const uint32_t*)(a.mask + ((long)(r >> 5) * a.ldm + c0) * 2);
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = ((w >> i) & 1u) ? gj_lds[c0 + i] : 0.f;
+        for (int i = 0; i < 8; ++i) v[i] = (((mp[i] >> (16 * half)) >> bit) & 1u) ? gj_lds[c0 + i] : 0.f;
         store8<T>(dpre + (long)r * a.ldd + c0, v);
     }
 }
@@ -441,11 +443,12 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     const int qpr = tile.cols >> 2;                       // four-element groups per row
     const int nq = tile.rows * qpr;
     const bool small = nq <= 64 && !tile.wt16;            // slab-parallel mode
-    const int lanes = small ? 4 : 1;
+    const int QL = nq <= 16 ? 16 : 64;                    // element-group slots; the other threads are slab lanes
+    const int lanes = small ? 256 / QL : 1;
 #pragma unroll 1
     for (int u = 0; u < (small ? 1 : 4); ++u) {
         int r, tc, sl0 = 0;
-        if (small) { const int qi = t & 63; sl0 = t >> 6; r = qi / qpr; tc = (qi - r * qpr) * 4; if (qi >= nq) r = tile.rows; }
+        if (small) { const int qi = t & (QL - 1); sl0 = t / QL; r = qi / qpr; tc = (qi - r * qpr) * 4; if (qi >= nq) r = tile.rows; }
         else { r = (t >> 4) + 16 * u; tc = (t & 15) * 4; }
         const bool valid = r < tile.rows && tc < tile.cols;
         const long off = (long)r * tile.ld + tc;
@@ -457,10 +460,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         if (small) {                                      // combine the slab lanes
             *(f32x4*)(tl + t * 4) = g;
             __syncthreads();
-            if (sl0 == 0) {
-#pragma unroll
-                for (int k = 1; k < 4; ++k) g += *(const f32x4*)(tl + (t + 64 * k) * 4);
-            }
+            if (sl0 == 0)
+                for (int k = 1; k < lanes; ++k) g += *(const f32x4*)(tl + (t + QL * k) * 4);
         }
         if (valid && sl0 == 0) {
             if (a.mode == ADAM_REDUCE_ONLY) *(f32x4*)(tile.flat + off) = g;

@@ -97,7 +97,7 @@ struct mrgan_handle {
 
     // activations (T = float | __bf16)
     void *zbuf, *h1, *hbn, *h2;
-    void* xin[5]; void* feat; uint32_t* mask[5]; int ldm[5];
+    void* xin[5]; void* feat; uint16_t* mask[5]; int ldm[5];
     void* dpre[5];
     void *dxfake, *dpre2g, *dhbn, *dpre1g;
     float* logits;
@@ -191,7 +191,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->es = h->bf16 ? 2 : 4;
     h->sync_stats = (c.flags & MRGAN_FLAG_SYNC_STATS) != 0;
     h->flat_grads = (c.flags & MRGAN_FLAG_FLAT_GRADS) != 0;
-    h->B = c.batch; h->S = (int)round_up(c.batch, SEG_ALIGN); h->tiles_m = ceil_div(c.batch, 128);
+    h->B = c.batch; h->S = (int)round_up(c.batch, SEG_ALIGN); h->tiles_m = ceil_div(c.batch, 64);   // 64-row column-sum partials
     h->Bg = c.batch * c.world;
     h->stat_count = (float)(h->sync_stats ? h->Bg : h->B);
     h->fm_scale = h->sync_stats ? 1.0f : 1.0f / (float)c.world;
@@ -258,8 +258,8 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->h1 = act(S, N1p); h->hbn = act(S, N1p); h->h2 = act(S, h->g[1].Np);
     for (int l = 0; l < 5; ++l) {
         h->xin[l] = act(3 * (size_t)S, h->d[l].Kp);
-        h->ldm[l] = h->d[l].Np / 32;
-        h->mask[l] = a.take<uint32_t>(3 * (size_t)S * h->ldm[l]);
+        h->ldm[l] = h->d[l].Np;                                   // lane-native relu mask: 2 x u16 per (32 rows, column)
+        h->mask[l] = a.take<uint16_t>(3 * (size_t)(S / 32) * h->ldm[l] * 2);
         h->dpre[l] = act(3 * (size_t)S, h->d[l].Np);
     }
     h->feat = act(3 * (size_t)S, h->Fp);
@@ -386,10 +386,10 @@ Epi base_epi(mrgan_handle* h) {
 
 // Y = act(X W + b): X [nb][S][Kp] -> out [nb][S][Np]
 int dense_fwd(mrgan_handle* h, const Dense& L, const void* x, int rows, int nb, void* out, int act, float sigma, uint32_t site,
-              uint32_t seg0, uint32_t* mask, int ldm, int cs_mode, float* cs1, float* cs2, bool noise_state, hipStream_t s) {
+              uint32_t seg0, uint16_t* mask, int ldm, int cs_mode, float* cs1, float* cs2, bool noise_state, hipStream_t s) {
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.M = rows; g.N = L.Np; g.K = L.Kp; g.nbatch = nb; g.splits = 1; g.kchunk = L.Kp; g.tiles_m = ceil_div(rows, 128);
+    g.M = rows; g.N = L.Np; g.K = L.Kp; g.nbatch = nb; g.splits = 1; g.kchunk = L.Kp; g.tiles_m = ceil_div(rows, 64);
     g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
     g.A = x; g.a_bs = (long)h->S * L.Kp; g.a_si = L.Kp; g.a_sk = 1;
     if (h->bf16) { g.B = L.W->wt16; g.b_sj = L.Kp; g.b_sk = 1; }
@@ -399,24 +399,24 @@ int dense_fwd(mrgan_handle* h, const Dense& L, const void* x, int rows, int nb, 
     g.e.act = act; g.e.n_valid = L.N; g.e.bias = L.b->p;
     g.e.out = out; g.e.out_bs = (long)h->S * L.Np; g.e.ldo = L.Np;
     g.e.sigma = sigma; g.e.site = site; g.e.seg0 = seg0;
-    g.e.mask = mask; g.e.mask_bs = (long)h->S * ldm; g.e.ldm = ldm;
+    g.e.mask = mask; g.e.mask_bs = (long)(h->S / 32) * ldm * 2; g.e.ldm = ldm;
     g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Np;
     return run_gemm(h, EPI_FWD, g, s);
 }
 
 // dX = (dY W^T) * act'(prev): dY [nb][S][Np] -> out [nb][S][Kp]
 int dense_dx(mrgan_handle* h, const Dense& L, const void* dy, int rows, int nb, void* out, int act, int n_valid,
-             const uint32_t* mask, int ldm, const void* hprev, int cs_mode, float* cs1, float* cs2, hipStream_t s) {
+             const uint16_t* mask, int ldm, const void* hprev, int cs_mode, float* cs1, float* cs2, hipStream_t s) {
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.M = rows; g.N = L.Kp; g.K = L.Np; g.nbatch = nb; g.splits = 1; g.kchunk = L.Np; g.tiles_m = ceil_div(rows, 128);
+    g.M = rows; g.N = L.Kp; g.K = L.Np; g.nbatch = nb; g.splits = 1; g.kchunk = L.Np; g.tiles_m = ceil_div(rows, 64);
     g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
     g.A = dy; g.a_bs = (long)h->S * L.Np; g.a_si = L.Np; g.a_sk = 1;
     g.B = h->bf16 ? (const void*)L.W->w16 : (const void*)L.W->p; g.b_sk = 1; g.b_sj = L.Np;
     g.e = base_epi(h);
     g.e.act = act; g.e.n_valid = n_valid;
     g.e.out = out; g.e.out_bs = (long)h->S * L.Kp; g.e.ldo = L.Kp;
-    g.e.mask = (uint32_t*)mask; g.e.mask_bs = (long)h->S * ldm; g.e.ldm = ldm;
+    g.e.mask = (uint16_t*)mask; g.e.mask_bs = (long)(h->S / 32) * ldm * 2; g.e.ldm = ldm;
     g.e.h = hprev; g.e.h_bs = (long)h->S * L.Kp; g.e.ldh = L.Kp;
     g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Kp;
     g.e.bn_mu = h->bn_mu; g.e.bn_rstd = h->bn_rstd;
@@ -1015,7 +1015,7 @@ int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a, con
         HIPCHK(hipMalloc((void**)&slabs, (size_t)g.splits * k * n * 4));
         g.e.slab = slabs; g.e.slab_stride = (long)k * n; g.e.ldo = n;
     }
-    g.tiles_m = ceil_div(g.M, 128);
+    g.tiles_m = ceil_div(g.M, 64);
     int r = bf ? launch_gemm_bf16(epi, g, s) : launch_gemm_f32(epi, g, s);
     if (!r) {
         if (op == 2) hipLaunchKernelGGL(sum_slabs_kernel, dim3(ceil_div((long)k * n, 256)), dim3(256), 0, s, slabs, g.splits, (long)k * n, (long)k * n, out);

@@ -7,6 +7,12 @@
 //   SLAB  dW[K,N] = X[M,K]^T dY[M,N], split over M into fp32 slabs  summed later inside the Adam kernel
 // All use 32x32 MFMA accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)),
 // so the epilogue code below is common to v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16.
+//
+// ReLU masks are stored in that same lane-native layout: one 16-bit word per (32-row block, column,
+// lane half), bit r = accumulator register r.  The forward epilogue builds the word in a register
+// (2 VALU ops per element) and stores it once per 32x32 sub-tile, fully coalesced; the backward
+// epilogue of the matching DX product loads it back the same way.  relu_mask_bit() decodes it for
+// kernels that walk rows and columns.
 #pragma once
 #include "common.h"
 
@@ -22,9 +28,9 @@ struct Epi {
     float sigma; uint32_t site; uint32_t seg0;  // FWD: out += sigma * N(0,1) drawn at (site, seg0+batch)
     uint32_t row0;                              // global row offset of this rank inside a segment
     uint64_t seed;
-    uint32_t* mask; long mask_bs; int ldm;      // FWD relu: written; DX relu: read. bit (row, col) at word col>>5
+    uint16_t* mask; long mask_bs; int ldm;      // FWD relu: written; DX relu: read. word ((row>>5)*ldm + col)*2 + half
     const void* h; long h_bs; int ldh;          // DX softplus: previous-layer output h (T); CS_SUM_XHAT: BN input h1
-    int cs_mode; float* cs1; float* cs2; int ldcs;   // per-row-tile column partial sums [batch*tiles_m + tile][ldcs]
+    int cs_mode; float* cs1; float* cs2; int ldcs;   // column partial sums per 64 rows: [batch*tiles_m + row/64][ldcs]
     const float* bn_mu; const float* bn_rstd;   // CS_SUM_XHAT
     float* slab; long slab_stride;              // SLAB: fp32 [split][rows][ldo]
     const DevState* st;
@@ -35,12 +41,19 @@ struct GemmArgs {
     int M, N, K;             // output rows / cols, reduction length (per batch)
     int nbatch, splits;      // grid.z = nbatch * splits ; splits > 1 only for SLAB
     int kchunk;              // reduction elements per split (multiple of the kernel's BK)
-    int tiles_m;             // ceil(M / BM)
+    int tiles_m;             // column-sum partial rows per batch = ceil(M / 64)
     int seg_stride, seg_rows;  // SLAB: reduction index v is a row of [nseg][seg_stride] with only v % seg_stride < seg_rows valid
     const void* A; long a_bs, a_si, a_sk;   // A(i,k) at A + b*a_bs + i*a_si + k*a_sk
     const void* B; long b_bs, b_sk, b_sj;   // B(k,j) at B + b*b_bs + k*b_sk + j*b_sj
     Epi e;
 };
+
+// bit of element (row, col) in the lane-native mask layout
+__device__ __forceinline__ uint32_t relu_mask_bit(const uint16_t* mask, int ldm, int row, int col) {
+    const int rr = row & 31;
+    const uint32_t w = mask[((long)(row >> 5) * ldm + col) * 2 + ((rr >> 2) & 1)];
+    return (w >> ((rr & 3) | ((rr >> 3) << 2))) & 1u;
+}
 
 // one wave's share of the block tile: MR x NR accumulators of 32x32.
 // STAGED: the block's output tile is first assembled in LDS (`tile`, [BM][bn] of T, the dead staging
@@ -72,69 +85,66 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         return;
     } else {
         T* out = (T*)e.out + (long)batch * e.out_bs;
-        uint32_t* mask = e.mask ? e.mask + (long)batch * e.mask_bs : nullptr;
+        uint16_t* mask = e.mask ? e.mask + (long)batch * e.mask_bs : nullptr;
         const T* hprev = e.h ? (const T*)e.h + (long)batch * e.h_bs : nullptr;
-        const uint32_t step = e.st ? e.st->iter : 0u;
-        const uint32_t nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)batch, step);
-        float cs1[NR], cs2[NR];
-#pragma unroll
-        for (int ni = 0; ni < NR; ++ni) { cs1[ni] = 0.f; cs2[ni] = 0.f; }
+        const bool noisy = EPI == EPI_FWD && e.sigma > 0.f && !(e.ablate & 1);
+        uint32_t nkey = 0;
+        if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)batch, e.st ? e.st->iter : 0u);
 
 #pragma unroll
         for (int ni = 0; ni < NR; ++ni) {
             const int col = col_blk + (wn * NR + ni) * 32 + lc;
             const bool colvalid = col < e.n_valid;
-            const bool colin = col < g.N;              // N is a multiple of 64, the block tile is 128 wide
-            float bias = 0.f, mu = 0.f, rstd = 0.f;
+            const bool colin = col < g.N;              // N is a multiple of 64, the block tile may be wider
+            float bias = 0.f;
             if constexpr (EPI == EPI_FWD) { if (colvalid && e.bias) bias = e.bias[col]; }
-            if constexpr (EPI == EPI_DX) {
-                if (e.cs_mode == CS_SUM_XHAT && colvalid) { mu = e.bn_mu[col]; rstd = e.bn_rstd[col]; }
-            }
+            const float sig = (noisy && colvalid) ? e.sigma : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) {
-                const int rbase = row_blk + (wm * MR + mi) * 32 + 4 * lh;
+                const int rsub = row_blk + (wm * MR + mi) * 32;            // first row of this 32x32 sub-tile
+                const long mword = ((long)(rsub >> 5) * e.ldm + col) * 2 + lh;
+                uint32_t mbits = 0;
+                if constexpr (EPI == EPI_DX) {
+                    if (e.act == ACT_RELU && colin && rsub < M) mbits = mask[mword];
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int r4 = rbase + 8 * q;
+                    const int r4 = rsub + 4 * lh + 8 * q;
                     float nz[4] = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (EPI == EPI_FWD) {
-                        if (e.sigma > 0.f && !(e.ablate & 1)) normal4(nkey, (e.row0 + (uint32_t)r4) >> 2, (uint32_t)col, nz);
+                        if (noisy) normal4(nkey, (e.row0 + (uint32_t)r4) >> 2, (uint32_t)col, nz);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int row = r4 + j;
-                        const bool rowvalid = row < M;
-                        float v = acc[mi][ni][4 * q + j];
+                        const int r = 4 * q + j, row = r4 + j;
+                        float v = acc[mi][ni][r];
+                        float o;
                         if constexpr (EPI == EPI_FWD) {
                             v += bias;
-                            if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
-                            else if (e.act == ACT_SOFTPLUS && !(e.ablate & 8)) v = softplus_f(v);
-                            if (!colvalid) v = 0.f;
-                            if (e.act == ACT_RELU && mask) {
-                                const unsigned long long bal = __ballot(v > 0.f);
-                                if (lc == 0 && rowvalid && colin)
-                                    mask[(long)row * e.ldm + (col >> 5)] = lh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-                            }
-                            if (rowvalid) { cs1[ni] += v; cs2[ni] += v * v; }
-                            if (colvalid) v += e.sigma * nz[j];
-                        } else {
                             if (e.act == ACT_RELU) {
-                                const uint32_t w = (rowvalid && colin) ? mask[(long)row * e.ldm + (col >> 5)] : 0u;
-                                v = ((w >> (col & 31)) & 1u) ? v : 0.f;
+                                // padding columns have zero weights and zero bias, so they come out exactly 0
+                                v = fmaxf(v, 0.f);
+                                mbits |= min(__builtin_bit_cast(uint32_t, v), 1u) << r;      // v >= +0: bit = (v != 0)
                             } else if (e.act == ACT_SOFTPLUS) {
-                                const float hv = (rowvalid && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
-                                if (!(e.ablate & 8)) v *= -expm1f(-hv);   // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
+                                v = colvalid ? ((e.ablate & 8) ? v : softplus_f(v)) : 0.f;
                             }
-                            if (!colvalid || !rowvalid) v = 0.f;
-                            cs1[ni] += v;
-                            if (e.cs_mode == CS_SUM_XHAT && rowvalid && colin) {
-                                const float h1 = Elem<T>::to_f32(hprev[(long)row * e.ldh + col]);
-                                cs2[ni] += v * (h1 - mu) * rstd;
+                            o = fmaf(sig, nz[j], v);
+                        } else {
+                            // rows >= M and padding columns arrive as exact zeros (zero-filled operands / zero weights)
+                            if (e.act == ACT_RELU) v = ((mbits >> r) & 1u) ? v : 0.f;
+                            else if (e.act == ACT_SOFTPLUS) {
+                                const float hv = (row < M && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
+                                if (!(e.ablate & 8)) v *= -expm1f(-hv);      // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
                             }
+                            o = v;
                         }
-                        if constexpr (STAGED) tile[(row - row_blk) * bn + (col - col_blk)] = Elem<T>::from_f32(v);
-                        else if (rowvalid && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(v);
+                        acc[mi][ni][r] = v;                                  // kept for the column-sum pass
+                        if constexpr (STAGED) tile[(row - row_blk) * bn + (col - col_blk)] = Elem<T>::from_f32(o);
+                        else if (row < M && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(o);
                     }
+                }
+                if constexpr (EPI == EPI_FWD) {
+                    if (e.act == ACT_RELU && mask && colin && rsub < M) mask[mword] = (uint16_t)mbits;
                 }
             }
         }
@@ -152,32 +162,64 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         }
 
         if (e.cs_mode != CS_NONE) {
-            // lanes l and l^32 hold the same column; then the WM waves stacked along M combine through LDS
-            const int wcols = NR * 32;
+            float cs1[NR], cs2[NR];
 #pragma unroll
             for (int ni = 0; ni < NR; ++ni) {
-                cs1[ni] += __shfl_xor(cs1[ni], 32, 64);
-                cs2[ni] += __shfl_xor(cs2[ni], 32, 64);
-            }
-            __syncthreads();                       // staging LDS is dead from here on
-            if (lh == 0) {
-#pragma unroll
-                for (int ni = 0; ni < NR; ++ni) {
-                    const int c = wn * wcols + ni * 32 + lc;
-                    lds[(wm * 2 + 0) * bn + c] = cs1[ni];
-                    lds[(wm * 2 + 1) * bn + c] = cs2[ni];
-                }
-            }
-            __syncthreads();
-            const int t = threadIdx.x;
-            if (t < bn) {
+                const int col = col_blk + (wn * NR + ni) * 32 + lc;
+                float mu = 0.f, rstd = 0.f;
+                if (e.cs_mode == CS_SUM_XHAT && col < e.n_valid) { mu = e.bn_mu[col]; rstd = e.bn_rstd[col]; }
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int w = 0; w < WM; ++w) { s1 += lds[(w * 2 + 0) * bn + t]; s2 += lds[(w * 2 + 1) * bn + t]; }
-                const long prow = (long)(batch * g.tiles_m + tile_m) * e.ldcs;
-                if (col_blk + t < e.ldcs) {
-                    e.cs1[prow + col_blk + t] = s1;
-                    if (e.cs_mode != CS_SUM) e.cs2[prow + col_blk + t] = s2;
+                for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row_blk + (wm * MR + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float v = (row < M) ? acc[mi][ni][r] : 0.f;
+                        s1 += v;
+                        if (e.cs_mode == CS_SUM_SQ) s2 += v * v;
+                        else if (e.cs_mode == CS_SUM_XHAT && row < M && col < g.N)
+                            s2 += v * (Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) - mu) * rstd;
+                    }
+                // lanes l and l^32 hold the same column
+                cs1[ni] = s1 + __shfl_xor(s1, 32, 64);
+                cs2[ni] = s2 + __shfl_xor(s2, 32, 64);
+            }
+            // partial sums have a fixed granularity of 64 rows: partial row = batch*cs_tiles + row/64
+            const long prow0 = (long)batch * g.tiles_m + (row_blk >> 6);
+            if constexpr (MR >= 2) {
+                // each wave covers 64 rows by itself: write its sums straight from registers
+                if (lh == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < NR; ++ni) {
+                        const int col = col_blk + (wn * NR + ni) * 32 + lc;
+                        if (col < e.ldcs && row_blk + wm * 64 < M) {
+                            e.cs1[(prow0 + wm) * e.ldcs + col] = cs1[ni];
+                            if (e.cs_mode != CS_SUM) e.cs2[(prow0 + wm) * e.ldcs + col] = cs2[ni];
+                        }
+                    }
+                }
+            } else {
+                // 32-row waves: the WM (= 2) waves stacked along M combine through LDS
+                const int wcols = NR * 32;
+                __syncthreads();
+                if (lh == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < NR; ++ni) {
+                        const int c = wn * wcols + ni * 32 + lc;
+                        lds[(wm * 2 + 0) * bn + c] = cs1[ni];
+                        lds[(wm * 2 + 1) * bn + c] = cs2[ni];
+                    }
+                }
+                __syncthreads();
+                const int t = threadIdx.x;
+                if (t < bn) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) { s1 += lds[(w * 2 + 0) * bn + t]; s2 += lds[(w * 2 + 1) * bn + t]; }
+                    if (col_blk + t < e.ldcs) {
+                        e.cs1[prow0 * e.ldcs + col_blk + t] = s1;
+                        if (e.cs_mode != CS_SUM) e.cs2[prow0 * e.ldcs + col_blk + t] = s2;
+                    }
                 }
             }
         }

@@ -1,6 +1,6 @@
 // bf16-in / fp32-accumulate MFMA GEMMs (v_mfma_f32_32x32x16_bf16) for gfx950.
 //
-// Two kernels, by where the reduction index lives in memory:
+// Kernels, by where the reduction index lives in memory:
 //   KC  ("k contiguous"): A[i][k], Bt[j][k] both have the reduction index innermost.
 //        forward  Y = X Wt^T   (A = activations [M][K], Bt = transposed bf16 weight copy [N][K])
 //        dX       dX = dY W^T  (A = dY [M][N], Bt = bf16 weight copy W [K][N]; reduction over N)
@@ -8,22 +8,35 @@
 //   KS  ("k strided"): A[k][i], B[k][j] have the reduction index outermost.
 //        dW = X^T dY (reduction over the batch rows): both operands are row-major activations, so the
 //        MFMA fragments (8 consecutive k for one row/col) are gathered with the hardware transposing
-//        LDS read ds_read_b64_tr_b16 from a [k][free] image padded to a 320-B row pitch.
-// Block tile 128x128, BK = 64, 4 waves (2x2), each wave 64x64 = 2x2 accumulators of 32x32.
-// Global->LDS goes through registers (16-B loads issued one tile ahead of the MFMAs that consume
-// them) so that out-of-range rows can be zero-filled and so later revisions can fuse transforms
-// into the staging path.
+//        LDS read ds_read_b64_tr_b16 from a [k][free] image.
+//
+// Staging is LDS-DMA: `buffer_load_dwordx4 ... offen lds` (16 B per lane, 1 KiB per wave-instruction)
+// straight from HBM/L2 into a double-buffered LDS image -- no VGPR round trip, no ds_write pass.
+//   * the LDS destination of a wave-instruction is lane-linear, so the bank-conflict swizzle is applied
+//     to the per-lane SOURCE address and undone by the same XOR on the fragment read;
+//   * the k-offset of a tile is the instruction's SGPR offset: advancing a tile costs no VALU;
+//   * rows past the end of an operand fall outside the buffer descriptor's range and arrive as zeros,
+//     which is what makes ragged M / N safe without per-lane predicates;
+//   * one raw s_barrier per k-tile: wait own loads (vmcnt(0)) -> barrier -> issue tile t+1 -> MFMA on
+//     tile t, so the next tile's loads are in flight under this tile's MFMAs.
+// Tile order is XCD-aware: consecutive block ids round-robin over the 8 XCDs, so each XCD is handed a
+// contiguous run of tiles that share the same A row panel in its private L2.
+//
+// Block = 4 waves as 2x2.  KC: BM x 128 x 64 with BM = 128 (wave 64x64) or 64 (wave 32x64, used when the
+// 128-row grid would not fill the chip).  KS: 128 x 128 x 64.
+// The weight-gradient product over ragged segments (batch not a multiple of 128) keeps a register-staged
+// kernel that can zero-fill arbitrary reduction rows.
 #include "gemm.h"
 
 namespace mrgan {
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int KC_TILE_BYTES = 128 * 128;        // 128 rows x 64 bf16
-constexpr int KS_PITCH = 320;                   // bytes per k-row: 256 data + 64 pad (tr-read conflict-free)
+constexpr int BN = 128, BK = 64;
+constexpr int KS_PITCH = 320;                   // register-staged KS image: 256 data + 64 pad bytes per k-row
 constexpr int KS_TILE_BYTES = 64 * KS_PITCH;
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int kc_off(int row, int chunk) {
     // 16-B chunk `chunk` (0..7) of row `row`; (row>>1)&7 spreads the 16 rows of a ds_read_b128
@@ -31,19 +44,152 @@ __device__ __forceinline__ int kc_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * KC_TILE_BYTES + 2048];   // + column-sum scratch
-    char* As = lds;
-    char* Bs = lds + KC_TILE_BYTES;
+// XCD-aware tile index: blocks b and b+8 share an XCD, so give XCD x the tiles [x*nt/8, (x+1)*nt/8)
+__device__ __forceinline__ int xcd_tile(int bid, int nt) {
+    return (nt & 7) == 0 ? (bid & 7) * (nt >> 3) + (bid >> 3) : bid;
+}
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+// =====================================================================================================
+// KC: forward and input-gradient products
+// =====================================================================================================
+template <int EPI, int BM>
+__global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
+    constexpr int MR = BM / 64;                      // 32-row sub-tiles per wave
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;     // wave-instructions per wave per k-tile (8 rows each)
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_n = blockIdx.x, tile_m = blockIdx.y, batch = blockIdx.z;
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int tidx = xcd_tile(blockIdx.x, ntn * ntm * g.nbatch);
+    const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
+    const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
     const int row_blk = tile_m * BM, col_blk = tile_n * BN;
 
-    const __bf16* A = (const __bf16*)g.A + (long)batch * g.a_bs;
-    const __bf16* B = (const __bf16*)g.B + (long)batch * g.b_bs;
+    // descriptors bounded at the operand's end: rows >= M (A) / >= N (Bt) read as zeros
+    const __bf16* Ab = (const __bf16*)g.A + (long)batch * g.a_bs;
+    const __bf16* Bb = (const __bf16*)g.B + (long)batch * g.b_bs;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)((long)g.M * g.a_si * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)((long)g.N * g.b_sj * 2), 0x00020000);
+
+    // lane -> (row within the instruction's 8 rows, swizzled source chunk)
+    const int lrow = lane >> 3, lp = lane & 7;
+    int voffA[A_INSTR], voffB[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int R = (wave * A_INSTR + i) * 8 + lrow;
+        voffA[i] = (int)(((long)(row_blk + R) * g.a_si + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int R = (wave * B_INSTR + i) * 8 + lrow;
+        voffB[i] = (int)(((long)(col_blk + R) * g.b_sj + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
+    }
+    auto issue = [&](int k0, int buf) {
+        char* a_dst = lds + buf * STAGE + wave * A_INSTR * 1024;
+        char* b_dst = lds + buf * STAGE + A_BYTES + wave * B_INSTR * 1024;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) glds16(rsA, a_dst + i * 1024, voffA[i], k0 * 2);
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) glds16(rsB, b_dst + i * 1024, voffB[i], k0 * 2);
+    };
+
+    f32x16 acc[MR][2];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nk = (g.e.ablate & 4) ? 0 : g.K / BK;
+    if (nk > 0) issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's loads of tile kt have landed
+        __builtin_amdgcn_s_barrier();                         // ... everyone's; and everyone finished tile kt-1
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) issue((kt + 1) * BK, (kt + 1) & 1);  // overwrites the buffer read during tile kt-1
+        const char* As = lds + (kt & 1) * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[MR], b[2];
+#pragma unroll
+            for (int mi = 0; mi < MR; ++mi) a[mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, ks * 2 + lh));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const bf16x8*)(Bs + kc_off((wn * 2 + ni) * 32 + lr, ks * 2 + lh));
+#pragma unroll
+            for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // the BM x 128 bf16 output tile is assembled in the now-dead first stage; column-sum scratch in the second
+    epilogue<__bf16, EPI, MR, 2, 2, true>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane, (float*)(lds + STAGE), BN,
+                                          (__bf16*)lds);
+}
+
+// =====================================================================================================
+// KS: weight-gradient product, LDS-DMA version (reduction rows contiguous and a multiple of 64)
+// LDS image [64 k][128 free] bf16 with 256-B rows; 16-B chunk c of k-row kr sits at chunk c ^ ((kr&3)<<2),
+// which makes the four k-rows x two 32-B column blocks that a 32-lane half of ds_read_b64_tr_b16 touches
+// hit eight distinct 32-B bank groups.
+// =====================================================================================================
+__device__ __forceinline__ bf16x8 ks_frag_swz(const char* tile, int fb, int ks, int lane) {
+    const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int f0 = fb + (g4 & 1) * 16;
+    const int m0 = ks * 16 + (g4 >> 1) * 8;                        // multiple of 8: (m0 + q) & 3 == q
+    const char* a0 = tile + (m0 + q) * 256 + ((((f0 >> 3) + (p >> 1)) ^ (q << 2)) << 4) + ((p & 1) << 3);
+    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 256));
+    const s16x8 tt = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, tt);
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_ks_fast_kernel(const GemmArgs g) {
+    constexpr int T_BYTES = 64 * 256, STAGE = 2 * T_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (g.N + 127) / 128, ntm = (g.M + 127) / 128;
+    const int tidx = xcd_tile(blockIdx.x, ntn * ntm * g.splits);
+    const int split = tidx / (ntn * ntm), rem = tidx - split * (ntn * ntm);
+    const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
+    const int row_blk = tile_m * 128, col_blk = tile_n * 128;
+    const int k_begin = split * g.kchunk;
+    const int k_end = (g.e.ablate & 4) ? k_begin : min(g.K, k_begin + g.kchunk);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((long)g.K * g.a_sk * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)((long)g.K * g.b_sk * 2), 0x00020000);
+    // a wave-instruction covers 4 k-rows x 256 B; lane -> (k-row, swizzled source chunk)
+    const int lrow = lane >> 4, lp = lane & 15;
+    int voffA[4], voffB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kr = (wave * 4 + i) * 4 + lrow;
+        const int c = lp ^ ((kr & 3) << 2);
+        voffA[i] = (int)(((long)kr * g.a_sk + row_blk + c * 8) * 2);
+        voffB[i] = (int)(((long)kr * g.b_sk + col_blk + c * 8) * 2);
+    }
+    auto issue = [&](int k0, int buf) {
+        char* a_dst = lds + buf * STAGE + wave * 4096;
+        char* b_dst = a_dst + T_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rsA, a_dst + i * 1024, voffA[i], (int)((long)k0 * g.a_sk * 2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rsB, b_dst + i * 1024, voffB[i], (int)((long)k0 * g.b_sk * 2));
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -53,40 +199,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[4], rb[4];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int cidx = t + 256 * u, row = cidx >> 3, c = cidx & 7;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            ra[u] = (row_blk + row < g.M) ? *(const u32x4*)(A + (long)(row_blk + row) * g.a_si + k0 + c * 8) : z;
-            rb[u] = (col_blk + row < g.N) ? *(const u32x4*)(B + (long)(col_blk + row) * g.b_sj + k0 + c * 8) : z;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int cidx = t + 256 * u, row = cidx >> 3, c = cidx & 7;
-            *(u32x4*)(As + kc_off(row, c)) = ra[u];
-            *(u32x4*)(Bs + kc_off(row, c)) = rb[u];
-        }
-    };
-
-    const int lr = lane & 31, lh = lane >> 5;
-    load_tile(0);
-    const int kc_end = (g.e.ablate & 4) ? 0 : g.K;
-    for (int k0 = 0; k0 < kc_end; k0 += BK) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (k0 + BK < g.K) load_tile(k0 + BK);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    if (nk > 0) issue(k_begin, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) issue(k_begin + (kt + 1) * BK, (kt + 1) & 1);
+        const char* As = lds + (kt & 1) * STAGE;
+        const char* Bs = As + T_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 a[2], b[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const bf16x8*)(As + kc_off((wm * 2 + mi) * 32 + lr, ks * 2 + lh));
+            for (int mi = 0; mi < 2; ++mi) a[mi] = ks_frag_swz(As, (wm * 2 + mi) * 32, ks, lane);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const bf16x8*)(Bs + kc_off((wn * 2 + ni) * 32 + lr, ks * 2 + lh));
+            for (int ni = 0; ni < 2; ++ni) b[ni] = ks_frag_swz(Bs, (wn * 2 + ni) * 32, ks, lane);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -95,12 +223,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
         }
     }
     __syncthreads();
-    // the 128x128 bf16 output tile (32 KB) is assembled in the now-dead staging buffers
-    epilogue<__bf16, EPI, 2, 2, 2, true>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
-                                         (float*)(lds + 2 * KC_TILE_BYTES), BN, (__bf16*)lds);
+    epilogue<__bf16, EPI_SLAB, 2, 2, 2>(acc, g, 0, split, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BN);
 }
 
-// transposed fragment: 8 consecutive k (rows of the LDS image) for free index f0 + (lane&15)
+// =====================================================================================================
+// KS, register-staged: handles reduction ranges with holes (segments of a batch that is not a multiple
+// of 128) by zero-filling rows per lane.  LDS image [64 k][128 free] with a 320-B pitch.
+// =====================================================================================================
 __device__ __forceinline__ bf16x8 ks_frag(const char* tile, int fb, int ks, int lane) {
     const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int f0 = fb + (g4 & 1) * 16;
@@ -109,8 +238,8 @@ __device__ __forceinline__ bf16x8 ks_frag(const char* tile, int fb, int ks, int 
     // (the v4i16 form: per-element use of the v4bf16 form's result is mis-folded by hipcc 7.2)
     const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
     const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * KS_PITCH));
-    const s16x8 t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, t);
+    const s16x8 tt = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, tt);
 }
 
 __global__ __launch_bounds__(256) void gemm_bf16_ks_kernel(const GemmArgs g) {
@@ -122,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_kernel(const GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int tile_n = blockIdx.x, tile_m = blockIdx.y;
     const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
-    const int row_blk = tile_m * BM, col_blk = tile_n * BN;
+    const int row_blk = tile_m * 128, col_blk = tile_n * BN;
     const int k_begin = split * g.kchunk;
     const int k_end = (g.e.ablate & 4) ? k_begin : min(g.K, k_begin + g.kchunk);
 
@@ -204,15 +333,33 @@ __global__ void tr_probe_kernel(unsigned short* out) {
 }  // namespace
 
 int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s) {
-    dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), g.nbatch * g.splits);
     dim3 block(256);
     if (epi == EPI_SLAB) {
         if (g.a_si != 1 || g.b_sj != 1) return -3;
-        hipLaunchKernelGGL(gemm_bf16_ks_kernel, grid, block, 0, s, g);
+        const bool dense_k = g.nbatch == 1 && (g.K % BK) == 0 && (g.kchunk % BK) == 0 &&
+                             (g.seg_rows >= g.seg_stride || g.K <= g.seg_rows) &&
+                             (long)g.K * g.a_sk * 2 < (1L << 31) && (long)g.K * g.b_sk * 2 < (1L << 31);
+        if (dense_k) {
+            dim3 grid(ceil_div(g.N, 128) * ceil_div(g.M, 128) * g.splits);
+            hipLaunchKernelGGL(gemm_bf16_ks_fast_kernel, grid, block, 0, s, g);
+        } else {
+            dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, 128), g.nbatch * g.splits);
+            hipLaunchKernelGGL(gemm_bf16_ks_kernel, grid, block, 0, s, g);
+        }
     } else {
         if (g.a_sk != 1 || g.b_sk != 1 || g.splits != 1 || (g.K % BK) != 0) return -3;
-        if (epi == EPI_FWD) hipLaunchKernelGGL(gemm_bf16_kc_kernel<EPI_FWD>, grid, block, 0, s, g);
-        else hipLaunchKernelGGL(gemm_bf16_kc_kernel<EPI_DX>, grid, block, 0, s, g);
+        if ((long)g.M * g.a_si * 2 >= (1L << 31) || (long)g.N * g.b_sj * 2 >= (1L << 31)) return -3;
+        const int ntn = ceil_div(g.N, BN);
+        const bool small = ceil_div(g.M, 128) * ntn * g.nbatch < 400;      // 64-row tiles when 128-row ones leave CUs idle
+        if (!small) {
+            dim3 grid(ceil_div(g.M, 128) * ntn * g.nbatch);
+            if (epi == EPI_FWD) hipLaunchKernelGGL((gemm_bf16_kc_kernel<EPI_FWD, 128>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_bf16_kc_kernel<EPI_DX, 128>), grid, block, 0, s, g);
+        } else {
+            dim3 grid(ceil_div(g.M, 64) * ntn * g.nbatch);
+            if (epi == EPI_FWD) hipLaunchKernelGGL((gemm_bf16_kc_kernel<EPI_FWD, 64>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_bf16_kc_kernel<EPI_DX, 64>), grid, block, 0, s, g);
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
