@@ -104,16 +104,39 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
 // column into (scale, shift) in LDS, then the block streams its rows 16 bytes per lane.
 // =========================================================================================
 constexpr int RB = 64;      // rows per block of the column-statistic kernels
+
+// Block-cooperative sum of `npart` partial rows for 256 consecutive columns starting at col0:
+// thread = (column quad t&63, partial lane t>>6); each lane folds every 4th partial row with 16-byte
+// loads, LDS combines the four lanes.  Result: out[c] for c in [0,256) valid after the barrier.
+__device__ __forceinline__ void fold_partials(const float* part, int npart, int ldcs, int col0, int ncols, float (*scr)[256], float* out) {
+    const int t = threadIdx.x, cq = (t & 63) * 4, pl = t >> 6;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (col0 + cq < ncols) {
+        int p = pl;
+        for (; p + 4 < npart; p += 8) {
+            s0 += *(const f32x4*)(part + (long)p * ldcs + col0 + cq);
+            s1 += *(const f32x4*)(part + (long)(p + 4) * ldcs + col0 + cq);
+        }
+        for (; p < npart; p += 4) s0 += *(const f32x4*)(part + (long)p * ldcs + col0 + cq);
+    }
+    s0 += s1;
+    *(f32x4*)(&scr[pl][cq]) = s0;
+    __syncthreads();
+    out[t] = (scr[0][t] + scr[1][t]) + (scr[2][t] + scr[3][t]);
+    __syncthreads();
+}
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
     __shared__ float sc[256], sh[256];
+    __shared__ float scr[4][256], f1[256], f2[256];
     const int t = threadIdx.x;
+    fold_partials(a.cs1, a.npart, a.ldcs, blockIdx.x * 256, a.ld, scr, f1);
+    fold_partials(a.cs2, a.npart, a.ldcs, blockIdx.x * 256, a.ld, scr, f2);
     {
         const int col = blockIdx.x * 256 + t;
         float scale = 0.f, shift = 0.f;
         if (col < a.ld) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int p = 0; p < a.npart; ++p) { s1 += a.cs1[(long)p * a.ldcs + col]; s2 += a.cs2[(long)p * a.ldcs + col]; }
+            const float s1 = f1[t], s2 = f2[t];
             const float mean = s1 / a.count;
             const float var = fmaxf(s2 / a.count - mean * mean, 0.f);
             const float rstd = 1.0f / sqrtf(var + a.eps);
@@ -145,14 +168,13 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
     __shared__ float cG[256];                                 // dgamma
     __shared__ float red[8][256];
     const int t = threadIdx.x;
+    fold_partials(a.cs1, a.npart, a.ldcs, blockIdx.x * 256, a.ld, red, cB);
+    fold_partials(a.cs2, a.npart, a.ldcs, blockIdx.x * 256, a.ld, red, cG);
     {
         const int col = blockIdx.x * 256 + t;
-        float dbeta = 0.f, dgamma = 0.f, g = 0.f, mu = 0.f, rs = 0.f;
-        if (col < a.ld) {
-            for (int p = 0; p < a.npart; ++p) { dbeta += a.cs1[(long)p * a.ldcs + col]; dgamma += a.cs2[(long)p * a.ldcs + col]; }
-            if (col < a.cols) { g = a.gamma[col]; mu = a.mu[col]; rs = a.rstd[col]; }
-        }
-        cA[t] = g * rs / a.count; cB[t] = dbeta; cG[t] = dgamma; cM[t] = mu; cR[t] = rs;
+        float g = 0.f, mu = 0.f, rs = 0.f;
+        if (col < a.cols) { g = a.gamma[col]; mu = a.mu[col]; rs = a.rstd[col]; }
+        cA[t] = g * rs / a.count; cM[t] = mu; cR[t] = rs;
     }
     __syncthreads();
     const int cg = t & 31, rl = t >> 5, c0 = blockIdx.x * 256 + cg * 8;
@@ -367,18 +389,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
     __shared__ float gj_lds[256];
     __shared__ float red[4];
+    __shared__ float scr[4][256], sf[256], sr[256];
     const int t = threadIdx.x;
+    fold_partials(a.cs, a.npart_fake, a.ldcs, 0, a.feat, scr, sf);
+    fold_partials(a.cs + (long)a.npart_fake * a.ldcs, a.npart_real, a.ldcs, 0, a.feat, scr, sr);
     float diff = 0.f;
-    if (t < a.feat_valid) {
-        float sf0 = 0.f, sf1 = 0.f, sr0 = 0.f, sr1 = 0.f;
-        int p = 0;
-        for (; p + 1 < a.npart_fake; p += 2) { sf0 += a.cs[(long)p * a.ldcs + t]; sf1 += a.cs[(long)(p + 1) * a.ldcs + t]; }
-        for (; p < a.npart_fake; ++p) sf0 += a.cs[(long)p * a.ldcs + t];
-        const float* csr = a.cs + (long)a.npart_fake * a.ldcs;
-        for (p = 0; p + 1 < a.npart_real; p += 2) { sr0 += csr[(long)p * a.ldcs + t]; sr1 += csr[(long)(p + 1) * a.ldcs + t]; }
-        for (; p < a.npart_real; ++p) sr0 += csr[(long)p * a.ldcs + t];
-        diff = ((sf0 + sf1) - (sr0 + sr1)) / a.count;
-    }
+    if (t < a.feat_valid) diff = (sf[t] - sr[t]) / a.count;
     gj_lds[t] = a.grad_scale * 2.0f / ((float)a.feat_valid * a.count) * diff;
     if (blockIdx.y == 0) {
         const float s = wave_sum(diff * diff);

@@ -86,6 +86,15 @@ __device__ __forceinline__ float softplus_f(float x) {
     // log1p(exp(x)) evaluated as max(x,0) + log1p(exp(-|x|))
     return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
 }
+// bf16 mode: hardware exp2/log2 (absolute error ~1e-7, far below bf16 resolution)
+__device__ __forceinline__ float softplus_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));          // exp(-|x|)
+    return fmaxf(x, 0.f) + 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + e);     // + ln(1 + e)
+}
+// 1 - exp(-h)
+__device__ __forceinline__ float one_minus_exp_neg_fast(float h) {
+    return 1.0f - __builtin_amdgcn_exp2f(-1.4426950408889634f * h);
+}
 __device__ __forceinline__ float sigmoid_f(float x) {
     return 1.0f / (1.0f + __expf(-x));
 }

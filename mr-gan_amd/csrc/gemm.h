@@ -19,6 +19,9 @@
 namespace mrgan {
 
 enum { EPI_FWD = 0, EPI_DX = 1, EPI_SLAB = 2 };
+// compile-time epilogue variant: activation in bits 0-1, then flags.  VAR_DYN keeps every decision at run time
+// (the fp32 parity kernels, where epilogue speed is irrelevant).
+enum { VAR_ACT_MASK = 3, VAR_NOISE = 4, VAR_MASK = 8, VAR_DYN = 64 };
 
 struct Epi {
     int act;                 // FWD: activation; DX: derivative applied (RELU mask / SOFTPLUS from h / LINEAR)
@@ -59,7 +62,7 @@ __device__ __forceinline__ uint32_t relu_mask_bit(const uint16_t* mask, int ldm,
 // STAGED: the block's output tile is first assembled in LDS (`tile`, [BM][bn] of T, the dead staging
 // buffers) and then written with coalesced 16-byte stores -- the accumulator layout holds one column
 // per lane, so direct stores would be 2-byte pieces at a row stride (store-issue bound).
-template <typename T, int EPI, int MR, int NR, int WM, bool STAGED = false>
+template <typename T, int EPI, int MR, int NR, int WM, bool STAGED = false, int VAR = VAR_DYN>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& g, int batch, int split,
                                          int tile_m, int row_blk, int col_blk, int wm, int wn, int lane,
                                          float* lds /* >= 2*WM*bn floats of scratch, disjoint from `tile` */,
@@ -84,10 +87,13 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             }
         return;
     } else {
+        constexpr bool DYN = (VAR & VAR_DYN) != 0;
+        const int act = DYN ? e.act : (VAR & VAR_ACT_MASK);
+        constexpr bool fast_math = sizeof(T) == 2;
         T* out = (T*)e.out + (long)batch * e.out_bs;
-        uint16_t* mask = e.mask ? e.mask + (long)batch * e.mask_bs : nullptr;
+        uint16_t* mask = (DYN || (VAR & VAR_MASK) || EPI == EPI_DX) && e.mask ? e.mask + (long)batch * e.mask_bs : nullptr;
         const T* hprev = e.h ? (const T*)e.h + (long)batch * e.h_bs : nullptr;
-        const bool noisy = EPI == EPI_FWD && e.sigma > 0.f && !(e.ablate & 1);
+        const bool noisy = EPI == EPI_FWD && (DYN ? e.sigma > 0.f : (VAR & VAR_NOISE) != 0) && !(e.ablate & 1);
         uint32_t nkey = 0;
         if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)batch, e.st ? e.st->iter : 0u);
 
@@ -105,7 +111,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                 const long mword = ((long)(rsub >> 5) * e.ldm + col) * 2 + lh;
                 uint32_t mbits = 0;
                 if constexpr (EPI == EPI_DX) {
-                    if (e.act == ACT_RELU && colin && rsub < M) mbits = mask[mword];
+                    if (act == ACT_RELU && colin && rsub < M) mbits = mask[mword];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -121,20 +127,21 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                         float o;
                         if constexpr (EPI == EPI_FWD) {
                             v += bias;
-                            if (e.act == ACT_RELU) {
+                            if (act == ACT_RELU) {
                                 // padding columns have zero weights and zero bias, so they come out exactly 0
                                 v = fmaxf(v, 0.f);
-                                mbits |= min(__builtin_bit_cast(uint32_t, v), 1u) << r;      // v >= +0: bit = (v != 0)
-                            } else if (e.act == ACT_SOFTPLUS) {
-                                v = colvalid ? ((e.ablate & 8) ? v : softplus_f(v)) : 0.f;
+                                if (mask) mbits |= min(__builtin_bit_cast(uint32_t, v), 1u) << r;      // v >= +0: bit = (v != 0)
+                            } else if (act == ACT_SOFTPLUS) {
+                                v = colvalid ? ((e.ablate & 8) ? v : (fast_math ? softplus_fast(v) : softplus_f(v))) : 0.f;
                             }
-                            o = fmaf(sig, nz[j], v);
+                            o = noisy ? fmaf(sig, nz[j], v) : v;
                         } else {
                             // rows >= M and padding columns arrive as exact zeros (zero-filled operands / zero weights)
-                            if (e.act == ACT_RELU) v = ((mbits >> r) & 1u) ? v : 0.f;
-                            else if (e.act == ACT_SOFTPLUS) {
+                            if (act == ACT_RELU) v = ((mbits >> r) & 1u) ? v : 0.f;
+                            else if (act == ACT_SOFTPLUS) {
                                 const float hv = (row < M && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
-                                if (!(e.ablate & 8)) v *= -expm1f(-hv);      // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
+                                // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
+                                if (!(e.ablate & 8)) v *= fast_math ? one_minus_exp_neg_fast(hv) : -expm1f(-hv);
                             }
                             o = v;
                         }
@@ -144,7 +151,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                     }
                 }
                 if constexpr (EPI == EPI_FWD) {
-                    if (e.act == ACT_RELU && mask && colin && rsub < M) mask[mword] = (uint16_t)mbits;
+                    if (act == ACT_RELU && mask && colin && rsub < M) mask[mword] = (uint16_t)mbits;
                 }
             }
         }

@@ -26,6 +26,8 @@
 // 128-row grid would not fill the chip).  KS: 128 x 128 x 64.
 // The weight-gradient product over ragged segments (batch not a multiple of 128) keeps a register-staged
 // kernel that can zero-fill arbitrary reduction rows.
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace mrgan {
@@ -56,12 +58,21 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst,
 // =====================================================================================================
 // KC: forward and input-gradient products
 // =====================================================================================================
-template <int EPI, int BM>
+// counted wait: all but the newest `n` LDS-DMA groups of LPT instructions each have landed
+template <int LPT>
+__device__ __forceinline__ void wait_groups(int n) {
+    if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, int BM, int NS, int VAR>
 __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
     constexpr int MR = BM / 64;                      // 32-row sub-tiles per wave
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;     // wave-instructions per wave per k-tile (8 rows each)
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    static_assert(NS >= 2 && NS <= 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char lds[];        // NS * STAGE bytes
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -110,14 +121,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
 
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = (g.e.ablate & 4) ? 0 : g.K / BK;
-    if (nk > 0) issue(0, 0);
+    // ring of NS stages, tiles are issued NS-1 ahead of their use
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nk) issue(p * BK, p);
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's loads of tile kt have landed
-        __builtin_amdgcn_s_barrier();                         // ... everyone's; and everyone finished tile kt-1
+        wait_groups<A_INSTR + B_INSTR>(min(NS - 2, nk - 1 - kt));   // this wave's loads of tile kt have landed
+        __builtin_amdgcn_s_barrier();                                 // ... everyone's; and everyone finished tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + 1 < nk) issue((kt + 1) * BK, (kt + 1) & 1);  // overwrites the buffer read during tile kt-1
-        const char* As = lds + (kt & 1) * STAGE;
+        if (kt + NS - 1 < nk) {                                       // refill the stage read during tile kt-1
+            int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
+            issue((kt + NS - 1) * BK, nb);
+        }
+        const char* As = lds + buf * STAGE;
         const char* Bs = As + A_BYTES;
+        buf = (buf + 1 == NS) ? 0 : buf + 1;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 a[MR], b[2];
@@ -134,8 +153,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
     }
     __syncthreads();
     // the BM x 128 bf16 output tile is assembled in the now-dead first stage; column-sum scratch in the second
-    epilogue<__bf16, EPI, MR, 2, 2, true>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane, (float*)(lds + STAGE), BN,
-                                          (__bf16*)lds);
+    epilogue<__bf16, EPI, MR, 2, 2, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane, (float*)(lds + STAGE), BN,
+                                               (__bf16*)lds);
+}
+
+template <int EPI, int BM, int NS, int VAR>
+int launch_kc(const GemmArgs& g, hipStream_t s) {
+    constexpr int STAGE = BM * 128 + BN * 128;
+    static bool attr_done = false;
+    auto kern = gemm_bf16_kc_kernel<EPI, BM, NS, VAR>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE) != hipSuccess) return -2;
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(g.M, BM) * ceil_div(g.N, BN) * g.nbatch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), NS * STAGE, s, g);
+    return 0;
 }
 
 // =====================================================================================================
@@ -155,9 +188,10 @@ __device__ __forceinline__ bf16x8 ks_frag_swz(const char* tile, int fb, int ks, 
     return __builtin_bit_cast(bf16x8, tt);
 }
 
+template <int NS>
 __global__ __launch_bounds__(256) void gemm_bf16_ks_fast_kernel(const GemmArgs g) {
     constexpr int T_BYTES = 64 * 256, STAGE = 2 * T_BYTES;
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    extern __shared__ __attribute__((aligned(16))) char lds[];        // NS * STAGE bytes
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -200,14 +234,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_fast_kernel(const GemmArgs g
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (k_end - k_begin + BK - 1) / BK;
-    if (nk > 0) issue(k_begin, 0);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nk) issue(k_begin + p * BK, p);
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_groups<8>(min(NS - 2, nk - 1 - kt));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 1 < nk) issue(k_begin + (kt + 1) * BK, (kt + 1) & 1);
-        const char* As = lds + (kt & 1) * STAGE;
+        if (kt + NS - 1 < nk) {
+            int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
+            issue(k_begin + (kt + NS - 1) * BK, nb);
+        }
+        const char* As = lds + buf * STAGE;
         const char* Bs = As + T_BYTES;
+        buf = (buf + 1 == NS) ? 0 : buf + 1;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 a[2], b[2];
@@ -224,6 +265,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_fast_kernel(const GemmArgs g
     }
     __syncthreads();
     epilogue<__bf16, EPI_SLAB, 2, 2, 2>(acc, g, 0, split, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BN);
+}
+
+template <int NS>
+int launch_ks_fast(const GemmArgs& g, hipStream_t s) {
+    constexpr int STAGE = 2 * 64 * 256;
+    static bool attr_done = false;
+    auto kern = gemm_bf16_ks_fast_kernel<NS>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE) != hipSuccess) return -2;
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(g.N, 128) * ceil_div(g.M, 128) * g.splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), NS * STAGE, s, g);
+    return 0;
 }
 
 // =====================================================================================================
@@ -332,35 +387,58 @@ __global__ void tr_probe_kernel(unsigned short* out) {
 }
 }  // namespace
 
+// tuning knobs (read once): MRGAN_KS_NS = ring depth of the weight-gradient kernel, MRGAN_KC_SMALL = tile-count
+// threshold below which the 64-row tile (3-stage ring) is used instead of the 128-row tile (2-stage ring)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// epilogue variants compiled for the bf16 path (anything else is a host-side error)
+template <int EPI, int VAR>
+static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
+    static const int small_thr = env_int("MRGAN_KC_SMALL", 800);
+    const bool small = ceil_div(g.M, 128) * ceil_div(g.N, BN) * g.nbatch < small_thr;
+    return small ? launch_kc<EPI, 64, 3, VAR>(g, s) : launch_kc<EPI, 128, 2, VAR>(g, s);
+}
+
+static int launch_kc_any(int epi, const GemmArgs& g, hipStream_t s) {
+    const Epi& e = g.e;
+    if (epi == EPI_FWD) {
+        const bool noise = e.sigma > 0.f, mask = e.mask != nullptr;
+        if (e.act == ACT_RELU && noise && mask) return launch_kc_tile<EPI_FWD, ACT_RELU | VAR_NOISE | VAR_MASK>(g, s);
+        if (e.act == ACT_RELU && !noise && mask) return launch_kc_tile<EPI_FWD, ACT_RELU | VAR_MASK>(g, s);
+        if (e.act == ACT_RELU && !noise && !mask) return launch_kc_tile<EPI_FWD, ACT_RELU>(g, s);
+        if (e.act == ACT_LINEAR && !mask) return noise ? launch_kc_tile<EPI_FWD, ACT_LINEAR | VAR_NOISE>(g, s)
+                                                       : launch_kc_tile<EPI_FWD, ACT_LINEAR>(g, s);
+        if (e.act == ACT_SOFTPLUS && !noise && !mask) return launch_kc_tile<EPI_FWD, ACT_SOFTPLUS>(g, s);
+        return -3;
+    }
+    if (e.act == ACT_RELU) return launch_kc_tile<EPI_DX, ACT_RELU>(g, s);
+    if (e.act == ACT_SOFTPLUS) return launch_kc_tile<EPI_DX, ACT_SOFTPLUS>(g, s);
+    return launch_kc_tile<EPI_DX, ACT_LINEAR>(g, s);
+}
+
 int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s) {
-    dim3 block(256);
+    int r = 0;
     if (epi == EPI_SLAB) {
         if (g.a_si != 1 || g.b_sj != 1) return -3;
         const bool dense_k = g.nbatch == 1 && (g.K % BK) == 0 && (g.kchunk % BK) == 0 &&
                              (g.seg_rows >= g.seg_stride || g.K <= g.seg_rows) &&
                              (long)g.K * g.a_sk * 2 < (1L << 31) && (long)g.K * g.b_sk * 2 < (1L << 31);
         if (dense_k) {
-            dim3 grid(ceil_div(g.N, 128) * ceil_div(g.M, 128) * g.splits);
-            hipLaunchKernelGGL(gemm_bf16_ks_fast_kernel, grid, block, 0, s, g);
+            static const int ns = env_int("MRGAN_KS_NS", 3);
+            r = ns == 2 ? launch_ks_fast<2>(g, s) : ns == 3 ? launch_ks_fast<3>(g, s) : launch_ks_fast<4>(g, s);
         } else {
             dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, 128), g.nbatch * g.splits);
-            hipLaunchKernelGGL(gemm_bf16_ks_kernel, grid, block, 0, s, g);
+            hipLaunchKernelGGL(gemm_bf16_ks_kernel, grid, dim3(256), 0, s, g);
         }
     } else {
         if (g.a_sk != 1 || g.b_sk != 1 || g.splits != 1 || (g.K % BK) != 0) return -3;
         if ((long)g.M * g.a_si * 2 >= (1L << 31) || (long)g.N * g.b_sj * 2 >= (1L << 31)) return -3;
-        const int ntn = ceil_div(g.N, BN);
-        const bool small = ceil_div(g.M, 128) * ntn * g.nbatch < 400;      // 64-row tiles when 128-row ones leave CUs idle
-        if (!small) {
-            dim3 grid(ceil_div(g.M, 128) * ntn * g.nbatch);
-            if (epi == EPI_FWD) hipLaunchKernelGGL((gemm_bf16_kc_kernel<EPI_FWD, 128>), grid, block, 0, s, g);
-            else hipLaunchKernelGGL((gemm_bf16_kc_kernel<EPI_DX, 128>), grid, block, 0, s, g);
-        } else {
-            dim3 grid(ceil_div(g.M, 64) * ntn * g.nbatch);
-            if (epi == EPI_FWD) hipLaunchKernelGGL((gemm_bf16_kc_kernel<EPI_FWD, 64>), grid, block, 0, s, g);
-            else hipLaunchKernelGGL((gemm_bf16_kc_kernel<EPI_DX, 64>), grid, block, 0, s, g);
-        }
+        r = launch_kc_any(epi, g, s);
     }
+    if (r) return r;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
