@@ -147,6 +147,9 @@ int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t ste
 int mrgan_debug_tr_probe(uint16_t* out1024_dev, mrgan_stream stream);
 /* timing experiments only (results become wrong): 1 no noise, 2 no GEMM epilogue, 4 no GEMM main loop, 8 no softplus */
 int mrgan_debug_ablate(int bits);
+/* average device time (us) of `reps` back-to-back launches of one bf16 product on scratch buffers:
+ * op 0 forward (relu+noise+mask), 1 input-gradient (relu mask), 2 weight-gradient with `splits` slabs */
+int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, int reps, float* avg_us);
 /* raw GEMM entry for kernel-level parity tests: op 0 = Y = act(X W + b), 1 = dX = dY W^T, 2 = dW = X^T dY.
  * fp32 device buffers in and out (converted internally when dtype = bf16). */
 int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a_dev, const float* b_dev, const float* bias_dev,

@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 __device__ __forceinline__ uint32_t noise_key(uint64_t seed, uint32_t site_seg, uint32_t step) {
     return mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) ^ mix32(step ^ mix32(site_seg))));
 }
-__device__ __forceinline__ float u16_01(uint32_t v) { return ((float)v + 0.5f) * (1.0f / 65536.0f); }   // inside (0,1)
+__device__ __forceinline__ float u16_01(uint32_t v) { return fmaf((float)v, 1.0f / 65536.0f, 0.5f / 65536.0f); }   // (v+0.5)/2^16, inside (0,1)
 
 // n[0..3]: standard normals for rows 4q..4q+3 at column col
 __device__ __forceinline__ void normal4(uint32_t key, uint32_t q, uint32_t col, float n[4]) {
@@ -70,8 +70,9 @@ __device__ __forceinline__ void normal4(uint32_t key, uint32_t q, uint32_t col, 
     const uint32_t x0 = mix32(a ^ (col * 0x85EBCA77u));
     const uint32_t x1 = mix32(((a << 16) | (a >> 16)) + col * 0xC2B2AE3Du + 1u);
     // r = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u); v_sin/v_cos take revolutions
-    const float r0 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u16_01(x0 & 0xFFFFu)));
-    const float r1 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u16_01(x1 & 0xFFFFu)));
+    // raw v_sqrt_f32 (1 ulp): the IEEE-exact sqrtf expands to ~15 instructions
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u16_01(x0 & 0xFFFFu)));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u16_01(x1 & 0xFFFFu)));
     const float t0 = u16_01(x0 >> 16), t1 = u16_01(x1 >> 16);
     n[0] = r0 * __builtin_amdgcn_cosf(t0);
     n[1] = r0 * __builtin_amdgcn_sinf(t0);

@@ -91,9 +91,13 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         const int act = DYN ? e.act : (VAR & VAR_ACT_MASK);
         constexpr bool fast_math = sizeof(T) == 2;
         T* out = (T*)e.out + (long)batch * e.out_bs;
-        uint16_t* mask = (DYN || (VAR & VAR_MASK) || EPI == EPI_DX) && e.mask ? e.mask + (long)batch * e.mask_bs : nullptr;
+        // specialised variants decide mask / noise at compile time (the launcher guarantees the pointers)
+        constexpr bool MASKED = !DYN && (EPI == EPI_DX || (VAR & VAR_MASK));
+        uint16_t* mask = nullptr;
+        if constexpr (MASKED) mask = e.mask + (long)batch * e.mask_bs;
+        else if (DYN && e.mask) mask = e.mask + (long)batch * e.mask_bs;
         const T* hprev = e.h ? (const T*)e.h + (long)batch * e.h_bs : nullptr;
-        const bool noisy = EPI == EPI_FWD && (DYN ? e.sigma > 0.f : (VAR & VAR_NOISE) != 0) && !(e.ablate & 1);
+        const bool noisy = EPI == EPI_FWD && (DYN ? (e.sigma > 0.f && !(e.ablate & 1)) : (VAR & VAR_NOISE) != 0);
         uint32_t nkey = 0;
         if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)batch, e.st ? e.st->iter : 0u);
 
@@ -130,7 +134,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             if (act == ACT_RELU) {
                                 // padding columns have zero weights and zero bias, so they come out exactly 0
                                 v = fmaxf(v, 0.f);
-                                if (mask) mbits |= min(__builtin_bit_cast(uint32_t, v), 1u) << r;      // v >= +0: bit = (v != 0)
+                                if (MASKED || mask) mbits |= min(__builtin_bit_cast(uint32_t, v), 1u) << r;    // v >= +0: bit = (v != 0)
                             } else if (act == ACT_SOFTPLUS) {
                                 v = colvalid ? ((e.ablate & 8) ? v : (fast_math ? softplus_fast(v) : softplus_f(v))) : 0.f;
                             }
@@ -151,7 +155,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                     }
                 }
                 if constexpr (EPI == EPI_FWD) {
-                    if (act == ACT_RELU && mask && colin && rsub < M) mask[mword] = (uint16_t)mbits;
+                    if (act == ACT_RELU && (MASKED || mask) && colin && rsub < M) mask[mword] = (uint16_t)mbits;
                 }
             }
         }
@@ -169,41 +173,58 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         }
 
         if (e.cs_mode != CS_NONE) {
-            float cs1[NR], cs2[NR];
+            // column sums per 64-row half of the wave tile (MR >= 2) or of the whole 32-row wave tile
+            constexpr int NH = MR >= 2 ? MR / 2 : 1, MH = MR >= 2 ? 2 : 1;
+            float cs1[NH][NR], cs2[NH][NR];
 #pragma unroll
-            for (int ni = 0; ni < NR; ++ni) {
-                const int col = col_blk + (wn * NR + ni) * 32 + lc;
-                float mu = 0.f, rstd = 0.f;
-                if (e.cs_mode == CS_SUM_XHAT && col < e.n_valid) { mu = e.bn_mu[col]; rstd = e.bn_rstd[col]; }
-                float s1 = 0.f, s2 = 0.f;
+            for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
-                for (int mi = 0; mi < MR; ++mi)
+                for (int ni = 0; ni < NR; ++ni) {
+                    const int col = col_blk + (wn * NR + ni) * 32 + lc;
+                    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row_blk + (wm * MR + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float v = (row < M) ? acc[mi][ni][r] : 0.f;
-                        s1 += v;
-                        if (e.cs_mode == CS_SUM_SQ) s2 += v * v;
-                        else if (e.cs_mode == CS_SUM_XHAT && row < M && col < g.N)
-                            s2 += v * (Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) - mu) * rstd;
+                    for (int m2 = 0; m2 < MH; ++m2) {
+                        const int mi = hh * MH + m2;
+                        const int rsub = row_blk + (wm * MR + mi) * 32 + 4 * lh;
+                        if (e.cs_mode == CS_SUM_XHAT) {
+                            const bool cok = col < e.n_valid && col < g.N;
+                            const float mu = cok ? e.bn_mu[col] : 0.f, rstd = cok ? e.bn_rstd[col] : 0.f;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = rsub + (r & 3) + 8 * (r >> 2);
+                                const bool ok = row < M;
+                                const float v = ok ? acc[mi][ni][r] : 0.f;
+                                const float hv = (ok && cok) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : mu;
+                                s1 += v; s2 = fmaf(v * (hv - mu), rstd, s2);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = (rsub + (r & 3) + 8 * (r >> 2) < M) ? acc[mi][ni][r] : 0.f;
+                                s1 += v; s2 = fmaf(v, v, s2);
+                            }
+                        }
                     }
-                // lanes l and l^32 hold the same column
-                cs1[ni] = s1 + __shfl_xor(s1, 32, 64);
-                cs2[ni] = s2 + __shfl_xor(s2, 32, 64);
-            }
+                    // lanes l and l^32 hold the same column
+                    cs1[hh][ni] = s1 + __shfl_xor(s1, 32, 64);
+                    cs2[hh][ni] = s2 + __shfl_xor(s2, 32, 64);
+                }
             // partial sums have a fixed granularity of 64 rows: partial row = batch*cs_tiles + row/64
             const long prow0 = (long)batch * g.tiles_m + (row_blk >> 6);
             if constexpr (MR >= 2) {
-                // each wave covers 64 rows by itself: write its sums straight from registers
+                // each wave covers whole 64-row groups by itself: write its sums straight from registers
                 if (lh == 0) {
 #pragma unroll
-                    for (int ni = 0; ni < NR; ++ni) {
-                        const int col = col_blk + (wn * NR + ni) * 32 + lc;
-                        if (col < e.ldcs && row_blk + wm * 64 < M) {
-                            e.cs1[(prow0 + wm) * e.ldcs + col] = cs1[ni];
-                            if (e.cs_mode != CS_SUM) e.cs2[(prow0 + wm) * e.ldcs + col] = cs2[ni];
+                    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+                        for (int ni = 0; ni < NR; ++ni) {
+                            const int col = col_blk + (wn * NR + ni) * 32 + lc;
+                            const long pr = prow0 + wm * NH + hh;
+                            if (col < e.ldcs && row_blk + (wm * NH + hh) * 64 < M) {
+                                e.cs1[pr * e.ldcs + col] = cs1[hh][ni];
+                                if (e.cs_mode != CS_SUM) e.cs2[pr * e.ldcs + col] = cs2[hh][ni];
+                            }
                         }
-                    }
                 }
             } else {
                 // 32-row waves: the WM (= 2) waves stacked along M combine through LDS
@@ -213,8 +234,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
 #pragma unroll
                     for (int ni = 0; ni < NR; ++ni) {
                         const int c = wn * wcols + ni * 32 + lc;
-                        lds[(wm * 2 + 0) * bn + c] = cs1[ni];
-                        lds[(wm * 2 + 1) * bn + c] = cs2[ni];
+                        lds[(wm * 2 + 0) * bn + c] = cs1[0][ni];
+                        lds[(wm * 2 + 1) * bn + c] = cs2[0][ni];
                     }
                 }
                 __syncthreads();

@@ -25,7 +25,7 @@ EXPORTS = [
     "mrgan_num_tensors", "mrgan_tensor_shape", "mrgan_set_weights", "mrgan_get_weights", "mrgan_get_slot",
     "mrgan_set_slot", "mrgan_get_iterations", "mrgan_set_iterations", "mrgan_disc_step", "mrgan_gen_step",
     "mrgan_train_pair", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
-    "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate",
+    "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time",
 ]
 PROF_CATEGORIES = ["gemm_fwd", "gemm_dx", "gemm_dw", "stage", "bn", "head", "fm", "adam", "other"]
 
@@ -300,3 +300,9 @@ def debug_tr_probe(device="cuda:0"):
     out = torch.zeros(1024, dtype=torch.int16, device=device)
     _check(load_library().mrgan_debug_tr_probe(_ptr(out), _stream()))
     return out.cpu().numpy().astype(np.uint16).reshape(2, 64, 8)
+
+
+def debug_gemm_time(op, m, n, k, nbatch=1, splits=1, reps=50):
+    us = C.c_float()
+    _check(load_library().mrgan_debug_gemm_time(op, m, n, k, nbatch, splits, reps, C.byref(us)))
+    return us.value

@@ -1,0 +1,31 @@
+"""Per-shape timing of the bf16 GEMM kernels on the shapes of BASELINE config 2 (B=4096, D=512).
+usage: python scripts/gemm_bench.py [ablate bits ...]   (env knobs of gemm_bf16.hip apply)"""
+import sys
+sys.path.insert(0, '.')
+import torch  # noqa: F401  (initialises HIP)
+from mr_gan_amd import engine as E
+
+B = 4096
+SHAPES = [  # (name, op, m, n, k, nbatch, splits)
+    ("fwd D1 3Bx512->1024", 0, B, 1024, 512, 3, 1),
+    ("fwd D2 3Bx1024->512", 0, B, 512, 1024, 3, 1),
+    ("fwd D3 3Bx512->256", 0, B, 256, 512, 3, 1),
+    ("fwd D4 3Bx256->256", 0, B, 256, 256, 3, 1),
+    ("fwd G2 Bx512->512", 0, B, 512, 512, 1, 1),
+    ("dx  D2 3B:512->1024", 1, B, 512, 1024, 3, 1),
+    ("dx  D3 3B:256->512", 1, B, 256, 512, 3, 1),
+    ("dw  D1 512x1024 /3B", 2, B, 1024, 512, 3, 8),
+    ("dw  D3 512x256 /3B", 2, B, 256, 512, 3, 16),
+    ("dw  D4 256x256 /3B", 2, B, 256, 256, 3, 16),
+]
+lib = E.load_library()
+bits = [int(a) for a in sys.argv[1:]] or [0]
+print("%-22s %8s " % ("shape", "GFLOP") + " ".join("abl%-3d us / TF   " % b for b in bits))
+for name, op, m, n, k, nb, sp in SHAPES:
+    gf = 2.0 * m * nb * n * k / 1e9
+    row = "%-22s %8.2f " % (name, gf)
+    for b in bits:
+        lib.mrgan_debug_ablate(b)
+        us = E.debug_gemm_time(op, m, n, k, nb, sp, reps=30)
+        row += "%8.1f /%6.0f   " % (us, gf / us * 1e-3 * 1e3)
+    print(row)
