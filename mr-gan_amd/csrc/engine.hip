@@ -964,6 +964,67 @@ int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t ste
 
 int mrgan_debug_ablate(int bits) { g_ablate = bits; return 0; }
 
+// Kernel-level timing of one bf16 product on scratch buffers (contents irrelevant): op 0 forward (relu + noise +
+// mask), 1 input-gradient (relu mask), 2 weight-gradient.  Returns the average device time of `reps` back-to-back
+// launches in microseconds (hipEvent pair around the whole run, so launch gaps are included).
+int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, int reps, float* avg_us) {
+    if ((n % 64) || (k % 64) || !avg_us) return fail(-1, "debug_gemm_time: bad argument");
+    const size_t rows = (size_t)m * nbatch;
+    const int a_cols = op == 1 ? n : k, o_cols = op == 1 ? k : n;
+    __bf16 *ta = nullptr, *tb = nullptr, *to = nullptr;
+    uint16_t* mask = nullptr; float* slabs = nullptr; float* bias = nullptr; DevState* st = nullptr;
+    HIPCHK(hipMalloc((void**)&ta, rows * std::max(a_cols, n) * 2));
+    HIPCHK(hipMalloc((void**)&tb, (size_t)std::max((size_t)k, rows) * n * 2));
+    HIPCHK(hipMalloc((void**)&to, rows * std::max(o_cols, n) * 2));
+    HIPCHK(hipMalloc((void**)&mask, (rows / 32 + 4) * std::max(n, k) * 4));
+    HIPCHK(hipMalloc((void**)&bias, (size_t)std::max(n, k) * 4));
+    HIPCHK(hipMalloc((void**)&st, sizeof(DevState) * 2));
+    HIPCHK(hipMemset(ta, 0x3c, rows * std::max(a_cols, n) * 2));      // bf16 ~0.0115 everywhere: finite, non-trivial bits
+    HIPCHK(hipMemset(tb, 0x3c, (size_t)std::max((size_t)k, rows) * n * 2));
+    HIPCHK(hipMemset(mask, 0x55, (rows / 32 + 4) * std::max(n, k) * 4));
+    HIPCHK(hipMemset(bias, 0, (size_t)std::max(n, k) * 4));
+    HIPCHK(hipMemset(st, 0, sizeof(DevState) * 2));
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.nbatch = nbatch; g.splits = 1; g.A = ta; g.B = tb;
+    g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
+    g.e.st = st; g.e.out = to; g.e.ablate = g_ablate; g.e.seed = 1;
+    int epi;
+    if (op == 0) {
+        epi = EPI_FWD; g.M = m; g.N = n; g.K = k; g.kchunk = k; g.a_bs = (long)m * k; g.a_si = k; g.a_sk = 1; g.b_sj = k; g.b_sk = 1;
+        g.e.act = ACT_RELU; g.e.n_valid = n; g.e.bias = bias; g.e.ldo = n; g.e.out_bs = (long)m * n;
+        g.e.sigma = 0.5f; g.e.site = 1; g.e.mask = mask; g.e.ldm = n; g.e.mask_bs = (long)(m / 32 + 1) * n * 2;
+    } else if (op == 1) {
+        epi = EPI_DX; g.M = m; g.N = k; g.K = n; g.kchunk = n; g.a_bs = (long)m * n; g.a_si = n; g.a_sk = 1; g.b_sk = 1; g.b_sj = n;
+        g.e.act = ACT_RELU; g.e.n_valid = k; g.e.ldo = k; g.e.out_bs = (long)m * k;
+        g.e.mask = mask; g.e.ldm = k; g.e.mask_bs = (long)(m / 32 + 1) * k * 2;
+    } else {
+        epi = EPI_SLAB; g.M = k; g.N = n; g.K = m * nbatch; g.nbatch = 1; g.splits = std::max(1, splits);
+        g.kchunk = (int)round_up(ceil_div(g.K, g.splits), 64);
+        g.a_si = 1; g.a_sk = k; g.b_sk = n; g.b_sj = 1;
+        HIPCHK(hipMalloc((void**)&slabs, (size_t)g.splits * k * n * 4));
+        g.e.slab = slabs; g.e.slab_stride = (long)k * n; g.e.ldo = n;
+    }
+    g.tiles_m = ceil_div(g.M, 64);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    int r = 0;
+    for (int i = 0; i < 3 && !r; ++i) r = launch_gemm_bf16(epi, g, 0);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps && !r; ++i) r = launch_gemm_bf16(epi, g, 0);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = 1e3f * ms / (float)reps;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(ta); hipFree(tb); hipFree(to); hipFree(mask); hipFree(bias); hipFree(st);
+    if (slabs) hipFree(slabs);
+    if (r) return fail(r, "debug_gemm_time: launch failed (%d)", r);
+    return 0;
+}
+
 int mrgan_debug_tr_probe(uint16_t* out, mrgan_stream stream) {
     if (!out) return fail(-1, "null argument");
     CHK(launch_tr_probe(out, (hipStream_t)stream));

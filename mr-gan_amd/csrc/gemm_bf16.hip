@@ -122,21 +122,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = (g.e.ablate & 4) ? 0 : g.K / BK;
     // ring of NS stages, tiles are issued NS-1 ahead of their use
+    const bool do_load = !(g.e.ablate & 32), do_mma = !(g.e.ablate & 16);      // timing experiments
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
-        if (p < nk) issue(p * BK, p);
+        if (p < nk && do_load) issue(p * BK, p);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         wait_groups<A_INSTR + B_INSTR>(min(NS - 2, nk - 1 - kt));   // this wave's loads of tile kt have landed
         __builtin_amdgcn_s_barrier();                                 // ... everyone's; and everyone finished tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + NS - 1 < nk) {                                       // refill the stage read during tile kt-1
+        if (kt + NS - 1 < nk && do_load) {                            // refill the stage read during tile kt-1
             int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
             issue((kt + NS - 1) * BK, nb);
         }
         const char* As = lds + buf * STAGE;
         const char* Bs = As + A_BYTES;
         buf = (buf + 1 == NS) ? 0 : buf + 1;
+        if (!do_mma) continue;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 a[MR], b[2];
@@ -234,21 +236,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_fast_kernel(const GemmArgs g
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (k_end - k_begin + BK - 1) / BK;
+    const bool do_load = !(g.e.ablate & 32), do_mma = !(g.e.ablate & 16);      // timing experiments
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
-        if (p < nk) issue(k_begin + p * BK, p);
+        if (p < nk && do_load) issue(k_begin + p * BK, p);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         wait_groups<8>(min(NS - 2, nk - 1 - kt));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + NS - 1 < nk) {
+        if (kt + NS - 1 < nk && do_load) {
             int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
             issue(k_begin + (kt + NS - 1) * BK, nb);
         }
         const char* As = lds + buf * STAGE;
         const char* Bs = As + T_BYTES;
         buf = (buf + 1 == NS) ? 0 : buf + 1;
+        if (!do_mma) continue;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 a[2], b[2];
