@@ -58,6 +58,38 @@ __device__ __forceinline__ uint32_t relu_mask_bit(const uint16_t* mask, int ldm,
     return (w >> ((rr & 3) | ((rr >> 3) << 2))) & 1u;
 }
 
+// Values the epilogue needs from global memory, fetched BEFORE the main loop so that their latency hides under
+// it (inside the epilogue each would be an exposed ~1 us round trip): the bias of the wave's columns (FWD) and
+// the relu-mask words of its 32x32 sub-tiles (DX).
+template <int MR, int NR>
+struct EpiPrefetch {
+    float bias[NR];
+    uint32_t mbits[MR][NR];
+};
+
+template <typename T, int EPI, int MR, int NR, int VAR>
+__device__ __forceinline__ void epilogue_prefetch(EpiPrefetch<MR, NR>& pf, const GemmArgs& g, int batch, int row_blk, int col_blk,
+                                                  int wm, int wn, int lane) {
+    const Epi& e = g.e;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int act = (VAR & 64) ? e.act : (VAR & 3);
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) {
+        const int col = col_blk + (wn * NR + ni) * 32 + lc;
+        pf.bias[ni] = 0.f;
+        if constexpr (EPI == EPI_FWD) { if (col < e.n_valid && e.bias) pf.bias[ni] = e.bias[col]; }
+#pragma unroll
+        for (int mi = 0; mi < MR; ++mi) {
+            pf.mbits[mi][ni] = 0;
+            if constexpr (EPI == EPI_DX) {
+                const int rsub = row_blk + (wm * MR + mi) * 32;
+                if (act == ACT_RELU && e.mask && col < g.N && rsub < g.M)
+                    pf.mbits[mi][ni] = (e.mask + (long)batch * e.mask_bs)[((long)(rsub >> 5) * e.ldm + col) * 2 + lh];
+            }
+        }
+    }
+}
+
 // one wave's share of the block tile: MR x NR accumulators of 32x32.
 // STAGED: the block's output tile is first assembled in LDS (`tile`, [BM][bn] of T, the dead staging
 // buffers) and then written with coalesced 16-byte stores -- the accumulator layout holds one column
@@ -66,7 +98,8 @@ template <typename T, int EPI, int MR, int NR, int WM, bool STAGED = false, int 
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& g, int batch, int split,
                                          int tile_m, int row_blk, int col_blk, int wm, int wn, int lane,
                                          float* lds /* >= 2*WM*bn floats of scratch, disjoint from `tile` */,
-                                         int bn /* block tile width */, T* tile = nullptr) {
+                                         int bn /* block tile width */, T* tile = nullptr,
+                                         const EpiPrefetch<MR, NR>* pf = nullptr) {
     const Epi& e = g.e;
     const int lc = lane & 31, lh = lane >> 5;
     const int M = g.M;
@@ -107,7 +140,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             const bool colvalid = col < e.n_valid;
             const bool colin = col < g.N;              // N is a multiple of 64, the block tile may be wider
             float bias = 0.f;
-            if constexpr (EPI == EPI_FWD) { if (colvalid && e.bias) bias = e.bias[col]; }
+            if constexpr (EPI == EPI_FWD) {
+                if (pf) bias = pf->bias[ni];
+                else if (colvalid && e.bias) bias = e.bias[col];
+            }
             const float sig = (noisy && colvalid) ? e.sigma : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) {
@@ -115,7 +151,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                 const long mword = ((long)(rsub >> 5) * e.ldm + col) * 2 + lh;
                 uint32_t mbits = 0;
                 if constexpr (EPI == EPI_DX) {
-                    if (act == ACT_RELU && colin && rsub < M) mbits = mask[mword];
+                    if (pf) mbits = pf->mbits[mi][ni];
+                    else if (act == ACT_RELU && colin && rsub < M) mbits = mask[mword];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -141,7 +178,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             o = noisy ? fmaf(sig, nz[j], v) : v;
                         } else {
                             // rows >= M and padding columns arrive as exact zeros (zero-filled operands / zero weights)
-                            if (act == ACT_RELU) v = ((mbits >> r) & 1u) ? v : 0.f;
+                            if (act == ACT_RELU)        // all-ones / zero from the mask bit, applied to the float's bits
+                                v = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & (uint32_t)(-(int)((mbits >> r) & 1u)));
                             else if (act == ACT_SOFTPLUS) {
                                 const float hv = (row < M && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
                                 // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
@@ -150,7 +188,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             o = v;
                         }
                         acc[mi][ni][r] = v;                                  // kept for the column-sum pass
-                        if constexpr (STAGED) tile[(row - row_blk) * bn + (col - col_blk)] = Elem<T>::from_f32(o);
+                        if constexpr (STAGED) { if (!(e.ablate & 64)) tile[(row - row_blk) * bn + (col - col_blk)] = Elem<T>::from_f32(o); else if (o == 12345.678f) tile[0] = Elem<T>::from_f32(o); }
                         else if (row < M && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(o);
                     }
                 }
@@ -165,6 +203,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             constexpr int EPV = 16 / (int)sizeof(T);               // elements per 16-byte chunk
             const int chunks_per_row = bn / EPV, bm = WM * MR * 32;
             __syncthreads();
+            if (!(e.ablate & 128))
             for (int cidx = threadIdx.x; cidx < bm * chunks_per_row; cidx += blockDim.x) {
                 const int r = cidx / chunks_per_row, c = cidx - r * chunks_per_row;
                 if (row_blk + r < M && col_blk + c * EPV < g.N)

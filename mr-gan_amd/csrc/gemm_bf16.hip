@@ -66,22 +66,28 @@ __device__ __forceinline__ void wait_groups(int n) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI, int BM, int NS, int VAR>
-__global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
-    constexpr int MR = BM / 64;                      // 32-row sub-tiles per wave
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;     // wave-instructions per wave per k-tile (8 rows each)
+// Block tile BM x BNT, WM x WN waves (each (BM/WM) x (BNT/WN), as MR x NR accumulators of 32x32), NS-stage ring.
+// LDS-DMA issue is the scarce resource of this loop (~60-100 issue cycles per 1 KiB wave-instruction), so the
+// achievable MFMA share grows with the tile's arithmetic intensity BM*BNT/(BM+BNT): 64x128 -> 43, 128x128 -> 64,
+// 256x128 -> 85, 256x256 -> 128 flop per staged byte.
+template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmArgs g) {
+    constexpr int NW = WM * WN;
+    constexpr int MR = BM / WM / 32, NR = BNT / WN / 32;   // 32x32 accumulators per wave
+    constexpr int A_BYTES = BM * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BNT / 8 / NW;   // wave-instructions per wave per k-tile (8 rows each)
     static_assert(NS >= 2 && NS <= 4, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char lds[];        // NS * STAGE bytes
+    static_assert(MR >= 1 && NR >= 1 && A_INSTR >= 1 && B_INSTR >= 1 && BM % (8 * NW) == 0 && BNT % (8 * NW) == 0, "tile/wave layout");
+    extern __shared__ __attribute__((aligned(16))) char lds[];        // max(NS * STAGE, BM * BNT * 2 + scratch) bytes
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = (g.N + BNT - 1) / BNT, ntm = (g.M + BM - 1) / BM;
     const int tidx = xcd_tile(blockIdx.x, ntn * ntm * g.nbatch);
     const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
     const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
-    const int row_blk = tile_m * BM, col_blk = tile_n * BN;
+    const int row_blk = tile_m * BM, col_blk = tile_n * BNT;
 
     // descriptors bounded at the operand's end: rows >= M (A) / >= N (Bt) read as zeros
     const __bf16* Ab = (const __bf16*)g.A + (long)batch * g.a_bs;
@@ -111,18 +117,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
         for (int i = 0; i < B_INSTR; ++i) glds16(rsB, b_dst + i * 1024, voffB[i], k0 * 2);
     };
 
-    f32x16 acc[MR][2];
+    f32x16 acc[MR][NR];
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NR; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // bias / relu-mask words of this wave's sub-tiles: their global-load latency hides under the main loop
+    EpiPrefetch<MR, NR> pf;
+    epilogue_prefetch<__bf16, EPI, MR, NR, VAR>(pf, g, batch, row_blk, col_blk, wm, wn, lane);
+
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = (g.e.ablate & 4) ? 0 : g.K / BK;
-    // ring of NS stages, tiles are issued NS-1 ahead of their use
     const bool do_load = !(g.e.ablate & 32), do_mma = !(g.e.ablate & 16);      // timing experiments
+    // ring of NS stages, tiles are issued NS-1 ahead of their use
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
         if (p < nk && do_load) issue(p * BK, p);
@@ -141,35 +151,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kc_kernel(const GemmArgs g) {
         if (!do_mma) continue;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[MR], b[2];
+            bf16x8 a[MR], b[NR];
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) a[mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, ks * 2 + lh));
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const bf16x8*)(Bs + kc_off((wn * 2 + ni) * 32 + lr, ks * 2 + lh));
+            for (int ni = 0; ni < NR; ++ni) b[ni] = *(const bf16x8*)(Bs + kc_off((wn * NR + ni) * 32 + lr, ks * 2 + lh));
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NR; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     }
     __syncthreads();
-    // the BM x 128 bf16 output tile is assembled in the now-dead first stage; column-sum scratch in the second
-    epilogue<__bf16, EPI, MR, 2, 2, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane, (float*)(lds + STAGE), BN,
-                                               (__bf16*)lds);
+    // the BM x BNT bf16 output tile is assembled at the start of the (now dead) ring, column-sum scratch behind it
+    epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
+                                                 (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf);
 }
 
-template <int EPI, int BM, int NS, int VAR>
+template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR>
 int launch_kc(const GemmArgs& g, hipStream_t s) {
-    constexpr int STAGE = BM * 128 + BN * 128;
+    constexpr int STAGE = BM * 128 + BNT * 128;
+    constexpr int OUT = BM * BNT * 2 + 4 * WM * BNT * 4;           // staged output tile + column-sum scratch
+    constexpr int LDS = NS * STAGE > OUT ? NS * STAGE : OUT;
     static bool attr_done = false;
-    auto kern = gemm_bf16_kc_kernel<EPI, BM, NS, VAR>;
+    auto kern = gemm_bf16_kc_kernel<EPI, BM, BNT, WM, WN, NS, VAR>;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE) != hipSuccess) return -2;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
         attr_done = true;
     }
-    dim3 grid(ceil_div(g.M, BM) * ceil_div(g.N, BN) * g.nbatch);
-    hipLaunchKernelGGL(kern, grid, dim3(256), NS * STAGE, s, g);
+    dim3 grid(ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, s, g);
     return 0;
 }
 
@@ -391,19 +403,32 @@ __global__ void tr_probe_kernel(unsigned short* out) {
 }
 }  // namespace
 
-// tuning knobs (read once): MRGAN_KS_NS = ring depth of the weight-gradient kernel, MRGAN_KC_SMALL = tile-count
-// threshold below which the 64-row tile (3-stage ring) is used instead of the 128-row tile (2-stage ring)
+// tuning knobs (read once): MRGAN_KS_NS = ring depth of the weight-gradient kernel, MRGAN_KC_CFG = forward/dX tile config
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
 // epilogue variants compiled for the bf16 path (anything else is a host-side error)
+// tile configs: 0 = 64x128 / 4 waves / 3 stages ; 1 = 128x128 / 4 waves / 2 stages ; 2 = 256x128 / 8 waves / 2 stages ;
+//               3 = 256x256 / 8 waves / 2 stages.  MRGAN_KC_CFG forces one; default picks by grid size.
 template <int EPI, int VAR>
 static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
-    static const int small_thr = env_int("MRGAN_KC_SMALL", 800);
-    const bool small = ceil_div(g.M, 128) * ceil_div(g.N, BN) * g.nbatch < small_thr;
-    return small ? launch_kc<EPI, 64, 3, VAR>(g, s) : launch_kc<EPI, 128, 2, VAR>(g, s);
+    static const int forced = env_int("MRGAN_KC_CFG", -1);
+    int cfg = forced;
+    if (cfg < 0) {
+        // measured on MI355X (scripts/gemm_bench.py): bigger tiles win once they still give >= ~1.5 blocks per CU
+        const int t128 = ceil_div(g.M, 128) * ceil_div(g.N, 128) * g.nbatch;
+        const int t256 = ceil_div(g.M, 256) * ceil_div(g.N, 256) * g.nbatch;
+        cfg = (EPI == EPI_DX && (g.N % 256) == 0 && t256 >= 192) ? 3 : t128 >= 384 ? 1 : 0;
+    }
+    if (cfg >= 2 && (g.N % 128) != 0) cfg = 0;
+    switch (cfg) {
+        case 1: return launch_kc<EPI, 128, 128, 2, 2, 2, VAR>(g, s);
+        case 2: return launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
+        case 3: return (g.N % 256) == 0 ? launch_kc<EPI, 256, 256, 2, 4, 2, VAR>(g, s) : launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
+        default: return launch_kc<EPI, 64, 128, 2, 2, 3, VAR>(g, s);
+    }
 }
 
 static int launch_kc_any(int epi, const GemmArgs& g, hipStream_t s) {
