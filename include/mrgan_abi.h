@@ -133,13 +133,15 @@ int mrgan_predict_logits(mrgan_handle* h, const float* x_dev, const int32_t* idx
  * last loss_gen.  reset != 0 zeroes the sums afterwards. */
 int mrgan_read_metrics(mrgan_handle* h, float* out8_host, int reset, mrgan_stream stream);
 
-/* Per-launch timing with hipEvent pairs recorded on the launch stream (bench.py's live roofline figure).
- * While profiling is on, mrgan_train_pair launches eagerly (no graph replay).  ms / launches have
- * MRGAN_PROF_NCAT entries: summed kernel time and launch count per category since mrgan_profile_begin. */
-enum { MRGAN_PROF_GEMM_FWD = 0, MRGAN_PROF_GEMM_DX = 1, MRGAN_PROF_GEMM_DW = 2, MRGAN_PROF_STAGE = 3, MRGAN_PROF_BN = 4,
-       MRGAN_PROF_HEAD = 5, MRGAN_PROF_FM = 6, MRGAN_PROF_ADAM = 7, MRGAN_PROF_OTHER = 8, MRGAN_PROF_NCAT = 9 };
+/* Per-launch timing with hipEvents recorded on the launch stream (bench.py's live roofline figure): one event
+ * behind every launch, a launch is charged the interval since the previous event (kernel + the dependent-launch
+ * gap in front of it).  While profiling is on, mrgan_train_pair launches eagerly (no graph replay).
+ * mrgan_profile_end returns, per distinct kernel instantiation (named as rocprofv3 prints it, MRGAN_PROF_NAME_LEN
+ * bytes each): summed time, launch count and summed ALGORITHMIC flops (2 x logical M*N*K of the dense layer). */
+enum { MRGAN_PROF_NAME_LEN = 96 };
 int mrgan_profile_begin(mrgan_handle* h);
-int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, float* ms, int32_t* launches);
+int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, int max_kernels, char* names, float* ms, int32_t* launches,
+                      double* flops, int* n_kernels);
 
 /* diagnostics used by the parity tests */
 int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,

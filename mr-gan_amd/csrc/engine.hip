@@ -61,7 +61,7 @@ struct Dense {
     float* slabs; int splits;   // weight-gradient slabs [nseg*splits][Kp][Np]
 };
 
-struct ProfRec { int cat; hipEvent_t e0, e1; };
+struct ProfRec { int cat; hipEvent_t ev; double flops; };      // ev = recorded after the launch; start = previous record's ev
 
 struct Arena {
     char* base = nullptr; size_t off = 0, cap = 0;
@@ -109,7 +109,7 @@ struct mrgan_handle {
     AdamTile *tiles_g_dev, *tiles_d_dev; int ntiles_g, ntiles_d;
 
     // per-launch hipEvent profiling (bench.py's live roofline measurement)
-    bool prof; std::vector<ProfRec> prof_recs;
+    bool prof; std::vector<ProfRec> prof_recs; std::vector<std::string> prof_names;
 
     // graph replay of (D step, G step)
     hipGraphExec_t graph_exec; bool graph_ready; int graph_cur; mrgan_disc_args graph_d; mrgan_gen_args graph_g;
@@ -346,31 +346,37 @@ int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n,
 // ------------------------------------------------------------------------------------------------
 // optional per-launch timing: one hipEvent pair per launch, on the launch stream
 // ------------------------------------------------------------------------------------------------
-int prof_begin(mrgan_handle* h, int cat, hipStream_t s) {
-    if (!h->prof) return -1;
+// One event per launch, recorded behind it; a launch's time is the interval since the previous event on the
+// stream, i.e. kernel time plus the dependent-launch gap in front of it (what a step really pays).
+int prof_cat(mrgan_handle* h, const char* name) {
+    for (size_t i = 0; i < h->prof_names.size(); ++i)
+        if (h->prof_names[i] == name) return (int)i;
+    h->prof_names.push_back(name);
+    return (int)h->prof_names.size() - 1;
+}
+void prof_mark(mrgan_handle* h, const char* name, double flops, hipStream_t s) {
+    if (!h->prof) return;
     ProfRec r;
-    r.cat = cat;
-    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
-    hipEventRecord(r.e0, s);
+    r.cat = prof_cat(h, name); r.flops = flops;
+    if (hipEventCreate(&r.ev) != hipSuccess) return;
     h->prof_recs.push_back(r);
-    return (int)h->prof_recs.size() - 1;
+    if (r.cat == prof_cat(h, "(start)")) hipEventRecord(r.ev, s);
 }
-void prof_end(mrgan_handle* h, int i, hipStream_t s) {
-    if (i >= 0) hipEventRecord(h->prof_recs[i].e1, s);
-}
-#define PROF(cat, call)                      \
-    do {                                     \
-        const int pi_ = prof_begin(h, cat, s); \
-        CHK(call);                           \
-        prof_end(h, pi_, s);                 \
+#define PROF(name, call)                                                     \
+    do {                                                                     \
+        if (h->prof && h->prof_recs.empty()) prof_mark(h, "(start)", 0, s);  \
+        CHK(call);                                                           \
+        if (h->prof) { prof_mark(h, name, 0, s); hipEventRecord(h->prof_recs.back().ev, s); } \
     } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // GEMM call sites
 // ------------------------------------------------------------------------------------------------
-int run_gemm(mrgan_handle* h, int epi, const GemmArgs& g, hipStream_t s) {
-    const int cat = epi == EPI_FWD ? MRGAN_PROF_GEMM_FWD : epi == EPI_DX ? MRGAN_PROF_GEMM_DX : MRGAN_PROF_GEMM_DW;
-    PROF(cat, h->bf16 ? launch_gemm_bf16(epi, g, s) : launch_gemm_f32(epi, g, s));
+int run_gemm(mrgan_handle* h, int epi, const GemmArgs& g, double algo_flops, hipStream_t s) {
+    const char* kname = "gemm";
+    if (h->prof && h->prof_recs.empty()) prof_mark(h, "(start)", 0, s);
+    CHK(h->bf16 ? launch_gemm_bf16(epi, g, s, &kname) : launch_gemm_f32(epi, g, s, &kname));
+    if (h->prof) { prof_mark(h, kname, algo_flops, s); hipEventRecord(h->prof_recs.back().ev, s); }
     return 0;
 }
 
@@ -401,7 +407,7 @@ int dense_fwd(mrgan_handle* h, const Dense& L, const void* x, int rows, int nb, 
     g.e.sigma = sigma; g.e.site = site; g.e.seg0 = seg0;
     g.e.mask = mask; g.e.mask_bs = (long)(h->S / 32) * ldm * 2; g.e.ldm = ldm;
     g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Np;
-    return run_gemm(h, EPI_FWD, g, s);
+    return run_gemm(h, EPI_FWD, g, 2.0 * rows * nb * L.K * L.N, s);
 }
 
 // dX = (dY W^T) * act'(prev): dY [nb][S][Np] -> out [nb][S][Kp]
@@ -420,7 +426,7 @@ int dense_dx(mrgan_handle* h, const Dense& L, const void* dy, int rows, int nb, 
     g.e.h = hprev; g.e.h_bs = (long)h->S * L.Kp; g.e.ldh = L.Kp;
     g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Kp;
     g.e.bn_mu = h->bn_mu; g.e.bn_rstd = h->bn_rstd;
-    return run_gemm(h, EPI_DX, g, s);
+    return run_gemm(h, EPI_DX, g, 2.0 * rows * nb * L.K * L.N, s);
 }
 
 // dW slabs = X^T dY.  The nseg segments ([nseg][S] rows, `rows` valid in each) form ONE virtual reduction
@@ -436,7 +442,7 @@ int dense_dw(mrgan_handle* h, const Dense& L, const void* x, const void* dy, int
     g.B = dy; g.b_sk = L.Np; g.b_sj = 1;
     g.e = base_epi(h);
     g.e.ldo = L.Np; g.e.slab = L.slabs; g.e.slab_stride = (long)L.Kp * L.Np;
-    return run_gemm(h, EPI_SLAB, g, s);
+    return run_gemm(h, EPI_SLAB, g, 2.0 * rows * nseg * L.K * L.N, s);
 }
 
 void* rowptr(mrgan_handle* h, void* base, long row, int ld) { return (char*)base + (size_t)row * ld * h->es; }
@@ -453,7 +459,7 @@ int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t 
         a.step_out = h->step_out; a.accum = h->accum;
         a.flat_tail = h->flat_d + h->flat_d_n;
     }
-    PROF(MRGAN_PROF_ADAM, launch_adam(a, s));
+    PROF("adam_kernel", launch_adam(a, s));
     return 0;
 }
 
@@ -463,8 +469,8 @@ int gen_fwd_head(mrgan_handle* h, hipStream_t s) {
                   true, s));
     if (h->sync_stats) {
         const int n = h->g[0].Np;
-        PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_bn1, h->tiles_m, n, n, h->r_bn_stats, s));
-        PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats + n, s));
+        PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn1, h->tiles_m, n, n, h->r_bn_stats, s));
+        PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats + n, s));
     }
     return 0;
 }
@@ -477,7 +483,7 @@ int gen_fwd_tail(mrgan_handle* h, int fake_seg_slot, uint32_t fake_seg_id, hipSt
     else { b.cs1 = h->cs_bn1; b.cs2 = h->cs_bn2; b.npart = h->tiles_m; }
     b.ldcs = n; b.count = h->stat_count; b.eps = h->cfg.bn_eps;
     b.gamma = h->gt[2].p; b.beta = h->gt[3].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
-    PROF(MRGAN_PROF_BN, launch_bn_apply(h->bf16, b, s));
+    PROF("bn_apply_kernel", launch_bn_apply(h->bf16, b, s));
     CHK(dense_fwd(h, h->g[1], h->hbn, h->B, 1, h->h2, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_NONE, nullptr, nullptr, true, s));
     // generator output + GaussianNoise(sigma0) = the discriminator's noisy input rows of the fake segment
     void* out = rowptr(h, h->xin[0], (long)fake_seg_slot * h->S, h->Dp);
@@ -527,7 +533,7 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         data_seg(st.s[0], h, a->x_lab_dev, a->idx_lab_dev, a->ld_x_lab, 0, 0, a->stream_mode);
         data_seg(st.s[1], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);
         stage_common(st, h, a->z_dev, a->stream_mode, 0, 2);
-        PROF(MRGAN_PROF_STAGE, launch_stage(h->bf16, st, s));
+        PROF("stage_kernel", launch_stage(h->bf16, st, s));
         CHK(gen_fwd_head(h, s));
     } else if (phase == MRGAN_D_MAIN) {
         CHK(gen_fwd_tail(h, 2, 2, s));
@@ -544,8 +550,8 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         hd.dpre = h->dpre[4]; hd.dpre_bs = (long)h->S * h->Fp; hd.ldd = h->Fp;
         hd.part = h->head_part; hd.part_stride = h->head_stride; hd.off_db = h->Fp * KMAX; hd.off_dbf = h->Fp * KMAX + KMAX;
         hd.loss_part = h->loss_part;
-        PROF(MRGAN_PROF_HEAD, launch_head(h->bf16, hd, s));
-        PROF(MRGAN_PROF_HEAD, launch_reduce_partials(h->head_part, h->nblk_head, h->head_stride, h->head_stride, h->head_groups,
+        PROF("head_kernel", launch_head(h->bf16, hd, s));
+        PROF("reduce_partials_kernel", launch_reduce_partials(h->head_part, h->nblk_head, h->head_stride, h->head_stride, h->head_groups,
                                                      h->head_red, s));
         for (int l = 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 3, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
@@ -569,14 +575,14 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         memset(&st, 0, sizeof st);
         data_seg(st.s[0], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);   // real rows -> slot 1
         stage_common(st, h, a->z_dev, a->stream_mode, a->stream_mode ? 1 : 0, 1);
-        PROF(MRGAN_PROF_STAGE, launch_stage(h->bf16, st, s));
+        PROF("stage_kernel", launch_stage(h->bf16, st, s));
         CHK(gen_fwd_head(h, s));
     } else if (phase == MRGAN_G_FEAT) {
         CHK(gen_fwd_tail(h, 0, 0, s));                                                          // fake rows -> slot 0
         CHK(disc_fwd_train(h, 2, true, s));
         if (h->sync_stats) {
-            PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_f, tm, h->Fp, h->Fp, h->r_fm, s));
-            PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm + h->Fp, s));
+            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f, tm, h->Fp, h->Fp, h->r_fm, s));
+            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm + h->Fp, s));
         }
     } else if (phase == MRGAN_G_BWD) {
         FmArgs f;
@@ -586,7 +592,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         f.ldcs = h->Fp; f.count = h->stat_count; f.grad_scale = h->fm_scale; f.feat = h->Fp; f.feat_valid = h->F;
         f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B;
         f.loss_out = h->step_out + 3; f.accum = h->accum + 3;
-        PROF(MRGAN_PROF_FM, launch_fm(h->bf16, f, s));
+        PROF("fm_kernel", launch_fm(h->bf16, f, s));
         for (int l = 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 1, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_NONE, nullptr, nullptr, s));
@@ -598,8 +604,8 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         CHK(dense_dx(h, h->g[1], h->dpre2g, B, 1, h->dhbn, ACT_LINEAR, h->g[0].N, nullptr, 0, h->h1, CS_SUM_XHAT, h->cs_dbeta,
                      h->cs_dgamma, s));
         if (h->sync_stats) {
-            PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_dbeta, tm, N1p, N1p, h->r_bn_bwd, s));
-            PROF(MRGAN_PROF_OTHER, launch_colsum_finalize(h->cs_dgamma, tm, N1p, N1p, h->r_bn_bwd + N1p, s));
+            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_dbeta, tm, N1p, N1p, h->r_bn_bwd, s));
+            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_dgamma, tm, N1p, N1p, h->r_bn_bwd + N1p, s));
         }
     } else if (phase == MRGAN_G_TAIL) {
         BnBwdArgs b;
@@ -609,7 +615,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         else { b.cs1 = h->cs_dbeta; b.cs2 = h->cs_dgamma; b.npart = tm; }
         b.ldcs = N1p; b.count = h->stat_count; b.gamma = h->gt[2].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
         b.db_part = h->db1g_part;
-        PROF(MRGAN_PROF_BN, launch_bn_bwd(h->bf16, b, s));
+        PROF("bn_bwd_kernel", launch_bn_bwd(h->bf16, b, s));
         CHK(dense_dw(h, h->g[2], h->h2, h->dxfake, B, 1, s));
         CHK(dense_dw(h, h->g[1], h->hbn, h->dpre2g, B, 1, s));
         CHK(dense_dw(h, h->g[0], h->zbuf, h->dpre1g, B, 1, s));
@@ -644,7 +650,7 @@ int eval_rows(mrgan_handle* h, const float* x, const int32_t* idx, long ld, cons
         sg.src = idx ? x : x + r0 * ld; sg.idx = idx ? idx + r0 : nullptr; sg.ld = ld; sg.rows = rows;
         sg.cols = h->cfg.d_in; sg.cols_pad = h->Dp; sg.out = h->xin[0]; sg.ldo = h->Dp;
         st.nseg = 1; st.seed = h->cfg.seed; st.cur = h->state + h->cur; st.next = nullptr;
-        PROF(MRGAN_PROF_STAGE, launch_stage(h->bf16, st, s));
+        PROF("stage_kernel", launch_stage(h->bf16, st, s));
         for (int l = 0; l < 5; ++l) {
             // one "segment" of `rows` contiguous rows: batch stride is irrelevant with nb = 1
             CHK(dense_fwd(h, h->d[l], h->xin[l], rows, 1, l < 4 ? h->xin[l + 1] : h->feat, ACT_RELU, 0.f, 0, 0, nullptr, 0, CS_NONE,
@@ -659,7 +665,7 @@ int eval_rows(mrgan_handle* h, const float* x, const int32_t* idx, long ld, cons
         if (!labels) hd.seg_kind[0] = HEAD_LOGITS;
         hd.st = h->state + h->cur; hd.labels_stream = 0;
         hd.logits = h->logits; hd.err_count = labels ? h->err_count : nullptr;
-        PROF(MRGAN_PROF_HEAD, launch_head(h->bf16, hd, s));
+        PROF("head_kernel", launch_head(h->bf16, hd, s));
         if (logits_out)
             HIPCHK(hipMemcpy2DAsync(logits_out + r0 * h->cfg.num_classes, sizeof(float) * h->cfg.num_classes, h->logits,
                                     sizeof(float) * KMAX, sizeof(float) * h->cfg.num_classes, rows, hipMemcpyDeviceToDevice, s));
@@ -941,17 +947,26 @@ int mrgan_profile_begin(mrgan_handle* h) {
     return 0;
 }
 
-int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, float* ms, int32_t* launches) {
-    if (!h || !ms || !launches) return fail(-1, "null argument");
+int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, int max_kernels, char* names, float* ms, int32_t* launches,
+                      double* flops, int* n_kernels) {
+    if (!h || !names || !ms || !launches || !flops || !n_kernels) return fail(-1, "null argument");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    for (int i = 0; i < MRGAN_PROF_NCAT; ++i) { ms[i] = 0.f; launches[i] = 0; }
-    for (auto& r : h->prof_recs) {
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms[r.cat] += t; launches[r.cat] += 1; }
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    const int n = std::min(max_kernels, (int)h->prof_names.size());
+    for (int i = 0; i < n; ++i) {
+        ms[i] = 0.f; launches[i] = 0; flops[i] = 0.0;
+        snprintf(names + (size_t)i * MRGAN_PROF_NAME_LEN, MRGAN_PROF_NAME_LEN, "%s", h->prof_names[i].c_str());
     }
-    h->prof_recs.clear();
+    for (size_t i = 0; i < h->prof_recs.size(); ++i) {
+        const ProfRec& r = h->prof_recs[i];
+        if (i > 0 && r.cat < n && h->prof_names[r.cat] != "(start)") {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, h->prof_recs[i - 1].ev, r.ev) == hipSuccess) { ms[r.cat] += t; launches[r.cat] += 1; flops[r.cat] += r.flops; }
+        }
+    }
+    for (auto& r : h->prof_recs) hipEventDestroy(r.ev);
+    h->prof_recs.clear(); h->prof_names.clear();
     h->prof = false;
+    *n_kernels = n;
     return 0;
 }
 

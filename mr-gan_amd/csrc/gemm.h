@@ -294,7 +294,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
 }
 
 // host-side launchers (gemm_f32.hip / gemm_bf16.hip)
-int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s);
-int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s);
+// kname (optional) receives the name of the kernel instantiation that was launched, spelled as rocprofv3 prints it
+int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
+int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
 
 }  // namespace mrgan

@@ -28,6 +28,8 @@
 // kernel that can zero-fill arbitrary reduction rows.
 #include <stdlib.h>
 
+#include <string>
+
 #include "gemm.h"
 
 namespace mrgan {
@@ -169,8 +171,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
                                                  (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf);
 }
 
+thread_local const char* g_last_kernel = "";
+
 template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR>
 int launch_kc(const GemmArgs& g, hipStream_t s) {
+    static const std::string name = "gemm_bf16_kc_kernel<" + std::to_string(EPI) + ", " + std::to_string(BM) + ", " +
+                                    std::to_string(BNT) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
+                                    std::to_string(NS) + ", " + std::to_string(VAR) + ">";
+    g_last_kernel = name.c_str();
     constexpr int STAGE = BM * 128 + BNT * 128;
     constexpr int OUT = BM * BNT * 2 + 4 * WM * BNT * 4;           // staged output tile + column-sum scratch
     constexpr int LDS = NS * STAGE > OUT ? NS * STAGE : OUT;
@@ -285,6 +293,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_fast_kernel(const GemmArgs g
 
 template <int NS>
 int launch_ks_fast(const GemmArgs& g, hipStream_t s) {
+    static const std::string name = "gemm_bf16_ks_fast_kernel<" + std::to_string(NS) + ">";
+    g_last_kernel = name.c_str();
     constexpr int STAGE = 2 * 64 * 256;
     static bool attr_done = false;
     auto kern = gemm_bf16_ks_fast_kernel<NS>;
@@ -448,7 +458,7 @@ static int launch_kc_any(int epi, const GemmArgs& g, hipStream_t s) {
     return launch_kc_tile<EPI_DX, ACT_LINEAR>(g, s);
 }
 
-int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s) {
+int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kname) {
     int r = 0;
     if (epi == EPI_SLAB) {
         if (g.a_si != 1 || g.b_sj != 1) return -3;
@@ -461,6 +471,7 @@ int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s) {
         } else {
             dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, 128), g.nbatch * g.splits);
             hipLaunchKernelGGL(gemm_bf16_ks_kernel, grid, dim3(256), 0, s, g);
+            g_last_kernel = "gemm_bf16_ks_kernel";
         }
     } else {
         if (g.a_sk != 1 || g.b_sk != 1 || g.splits != 1 || (g.K % BK) != 0) return -3;
@@ -468,6 +479,7 @@ int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s) {
         r = launch_kc_any(epi, g, s);
     }
     if (r) return r;
+    if (kname) *kname = g_last_kernel;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

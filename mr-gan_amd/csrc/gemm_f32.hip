@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 }
 }  // namespace
 
-int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s) {
+int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s, const char** kname) {
+    static const char* names[3] = {"gemm_f32_kernel<0>", "gemm_f32_kernel<1>", "gemm_f32_kernel<2>"};
+    if (kname && epi >= 0 && epi < 3) *kname = names[epi];
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), g.nbatch * g.splits);
     dim3 block(256);
     switch (epi) {

@@ -27,7 +27,7 @@ EXPORTS = [
     "mrgan_train_pair", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
     "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time",
 ]
-PROF_CATEGORIES = ["gemm_fwd", "gemm_dx", "gemm_dw", "stage", "bn", "head", "fm", "adam", "other"]
+PROF_NAME_LEN = 96
 
 
 class Config(C.Structure):
@@ -259,12 +259,18 @@ class Engine(object):
     def profile_begin(self):
         _check(self.lib.mrgan_profile_begin(self.handle))
 
-    def profile_end(self):
-        """-> {category: (total ms, launches)} of per-launch hipEvent timings since profile_begin"""
-        n = len(PROF_CATEGORIES)
-        ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
-        _check(self.lib.mrgan_profile_end(self.handle, _stream(), ms, cnt))
-        return {PROF_CATEGORIES[i]: (ms[i], cnt[i]) for i in range(n)}
+    def profile_end(self, max_kernels=64):
+        """-> {kernel instantiation name: (total ms, launches, algorithmic flops)} since profile_begin"""
+        names = C.create_string_buffer(max_kernels * PROF_NAME_LEN)
+        ms, cnt = (C.c_float * max_kernels)(), (C.c_int32 * max_kernels)()
+        fl, n = (C.c_double * max_kernels)(), C.c_int()
+        _check(self.lib.mrgan_profile_end(self.handle, _stream(), max_kernels, names, ms, cnt, fl, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = names.raw[i * PROF_NAME_LEN:(i + 1) * PROF_NAME_LEN].split(b"\0")[0].decode()
+            if name != "(start)":
+                out[name] = (ms[i], cnt[i], fl[i])
+        return out
 
     def region(self, which):
         """fp32 torch view of a workspace region (aliases library memory: used for all-reduce)."""
