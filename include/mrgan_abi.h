@@ -147,7 +147,7 @@ int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, int max_kernels, cha
 int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,
                       float* out_dev, mrgan_stream stream);
 int mrgan_debug_tr_probe(uint16_t* out1024_dev, mrgan_stream stream);
-/* timing experiments only (results become wrong): 1 no noise, 2 no GEMM epilogue, 4 no GEMM main loop, 8 no softplus */
+/* timing experiments only (results become wrong): 2 = skip the GEMM epilogues, 4 = skip the GEMM main loops */
 int mrgan_debug_ablate(int bits);
 /* average device time (us) of `reps` back-to-back launches of one bf16 product on scratch buffers:
  * op 0 forward (relu+noise+mask), 1 input-gradient (relu mask), 2 weight-gradient with `splits` slabs */

@@ -986,6 +986,7 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
     if ((n % 64) || (k % 64) || !avg_us) return fail(-1, "debug_gemm_time: bad argument");
     const size_t rows = (size_t)m * nbatch;
     const int a_cols = op == 1 ? n : k, o_cols = op == 1 ? k : n;
+    if (op < 0 || op > 4) return fail(-1, "debug_gemm_time: bad op");
     __bf16 *ta = nullptr, *tb = nullptr, *to = nullptr;
     uint16_t* mask = nullptr; float* slabs = nullptr; float* bias = nullptr; DevState* st = nullptr;
     HIPCHK(hipMalloc((void**)&ta, rows * std::max(a_cols, n) * 2));
@@ -1005,10 +1006,11 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
     g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
     g.e.st = st; g.e.out = to; g.e.ablate = g_ablate; g.e.seed = 1;
     int epi;
-    if (op == 0) {
+    if (op == 0 || op == 3 || op == 4) {       // 0: relu + noise + mask ; 3: relu + mask ; 4: plain relu
         epi = EPI_FWD; g.M = m; g.N = n; g.K = k; g.kchunk = k; g.a_bs = (long)m * k; g.a_si = k; g.a_sk = 1; g.b_sj = k; g.b_sk = 1;
         g.e.act = ACT_RELU; g.e.n_valid = n; g.e.bias = bias; g.e.ldo = n; g.e.out_bs = (long)m * n;
-        g.e.sigma = 0.5f; g.e.site = 1; g.e.mask = mask; g.e.ldm = n; g.e.mask_bs = (long)(m / 32 + 1) * n * 2;
+        g.e.sigma = op == 0 ? 0.5f : 0.f; g.e.site = 1;
+        if (op != 4) { g.e.mask = mask; g.e.ldm = n; g.e.mask_bs = (long)(m / 32 + 1) * n * 2; }
     } else if (op == 1) {
         epi = EPI_DX; g.M = m; g.N = k; g.K = n; g.kchunk = n; g.a_bs = (long)m * n; g.a_si = n; g.a_sk = 1; g.b_sk = 1; g.b_sj = n;
         g.e.act = ACT_RELU; g.e.n_valid = k; g.e.ldo = k; g.e.out_bs = (long)m * k;
@@ -1021,6 +1023,14 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
         g.e.slab = slabs; g.e.slab_stride = (long)k * n; g.e.ldo = n;
     }
     g.tiles_m = ceil_div(g.M, 64);
+#ifdef MRGAN_STAMPS
+    unsigned long long* stamps = nullptr;
+    if (op != 2) {
+        HIPCHK(hipMalloc((void**)&stamps, 4096 * 8 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(stamps, 0, 4096 * 8 * sizeof(unsigned long long)));
+        g.e.slab = (float*)stamps;
+    }
+#endif
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     int r = 0;
@@ -1033,6 +1043,17 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = 1e3f * ms / (float)reps;
+#ifdef MRGAN_STAMPS
+    if (stamps) {
+        std::vector<unsigned long long> hs(4096 * 8);
+        hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        double tot[6] = {0, 0, 0, 0, 0, 0}; int nb = 0;
+        for (int b = 0; b < 4096; ++b) if (hs[b * 8 + 2]) { ++nb; for (int i = 0; i < 6; ++i) tot[i] += (double)hs[b * 8 + i]; }
+        if (nb) fprintf(stderr, "  stamps (kcycles per block, %d blocks): setup %.1f | fill %.1f | mainloop %.1f | barrier %.1f | epilogue %.1f | tail-barrier %.1f\n",
+                        nb, tot[0] / nb / 1e3, tot[1] / nb / 1e3, tot[2] / nb / 1e3, tot[3] / nb / 1e3, tot[4] / nb / 1e3, tot[5] / nb / 1e3);
+        hipFree(stamps);
+    }
+#endif
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(ta); hipFree(tb); hipFree(to); hipFree(mask); hipFree(bias); hipFree(st);
     if (slabs) hipFree(slabs);

@@ -28,6 +28,7 @@
 // kernel that can zero-fill arbitrary reduction rows.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <string>
 
 #include "gemm.h"
@@ -86,89 +87,113 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = (g.N + BNT - 1) / BNT, ntm = (g.M + BM - 1) / BM;
-    const int tidx = xcd_tile(blockIdx.x, ntn * ntm * g.nbatch);
-    const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
-    const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
-    const int row_blk = tile_m * BM, col_blk = tile_n * BNT;
-
-    // descriptors bounded at the operand's end: rows >= M (A) / >= N (Bt) read as zeros
-    const __bf16* Ab = (const __bf16*)g.A + (long)batch * g.a_bs;
-    const __bf16* Bb = (const __bf16*)g.B + (long)batch * g.b_bs;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)((long)g.M * g.a_si * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)((long)g.N * g.b_sj * 2), 0x00020000);
-
-    // lane -> (row within the instruction's 8 rows, swizzled source chunk)
-    const int lrow = lane >> 3, lp = lane & 7;
-    int voffA[A_INSTR], voffB[B_INSTR];
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        const int R = (wave * A_INSTR + i) * 8 + lrow;
-        voffA[i] = (int)(((long)(row_blk + R) * g.a_si + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
-    }
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int R = (wave * B_INSTR + i) * 8 + lrow;
-        voffB[i] = (int)(((long)(col_blk + R) * g.b_sj + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
-    }
-    auto issue = [&](int k0, int buf) {
-        char* a_dst = lds + buf * STAGE + wave * A_INSTR * 1024;
-        char* b_dst = lds + buf * STAGE + A_BYTES + wave * B_INSTR * 1024;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) glds16(rsA, a_dst + i * 1024, voffA[i], k0 * 2);
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) glds16(rsB, b_dst + i * 1024, voffB[i], k0 * 2);
-    };
-
-    f32x16 acc[MR][NR];
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // bias / relu-mask words of this wave's sub-tiles: their global-load latency hides under the main loop
-    EpiPrefetch<MR, NR> pf;
-    epilogue_prefetch<__bf16, EPI, MR, NR, VAR>(pf, g, batch, row_blk, col_blk, wm, wn, lane);
-
+    const int ntiles = ntn * ntm * g.nbatch;
+    const int lrow = lane >> 3, lp = lane & 7;       // lane -> (row within an instruction's 8 rows, 16-B chunk)
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = (g.e.ablate & 4) ? 0 : g.K / BK;
-    const bool do_load = !(g.e.ablate & 32), do_mma = !(g.e.ablate & 16);      // timing experiments
-    // ring of NS stages, tiles are issued NS-1 ahead of their use
+
+    // Persistent block: walks the tiles bid, bid + grid, ...  One tile's output stores drain while the next tile's
+    // loads and MFMAs run, and co-resident blocks drift out of phase instead of all hitting HBM at once.
+#ifdef MRGAN_STAMPS
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define STAMP(i)
+#endif
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tidx = xcd_tile(tl, ntiles);
+        const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
+        const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
+        const int row_blk = tile_m * BM, col_blk = tile_n * BNT;
+
+        // descriptors bounded at the operand's end: rows >= M (A) / >= N (Bt) read as zeros
+        const __bf16* Ab = (const __bf16*)g.A + (long)batch * g.a_bs;
+        const __bf16* Bb = (const __bf16*)g.B + (long)batch * g.b_bs;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)((long)g.M * g.a_si * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)((long)g.N * g.b_sj * 2), 0x00020000);
+        int voffA[A_INSTR], voffB[B_INSTR];          // swizzled per-lane source offsets
 #pragma unroll
-    for (int p = 0; p < NS - 1; ++p)
-        if (p < nk && do_load) issue(p * BK, p);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        wait_groups<A_INSTR + B_INSTR>(min(NS - 2, nk - 1 - kt));   // this wave's loads of tile kt have landed
-        __builtin_amdgcn_s_barrier();                                 // ... everyone's; and everyone finished tile kt-1
-        asm volatile("" ::: "memory");
-        if (kt + NS - 1 < nk && do_load) {                            // refill the stage read during tile kt-1
-            int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
-            issue((kt + NS - 1) * BK, nb);
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int R = (wave * A_INSTR + i) * 8 + lrow;
+            voffA[i] = (int)(((long)(row_blk + R) * g.a_si + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
         }
-        const char* As = lds + buf * STAGE;
-        const char* Bs = As + A_BYTES;
-        buf = (buf + 1 == NS) ? 0 : buf + 1;
-        if (!do_mma) continue;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[MR], b[NR];
-#pragma unroll
-            for (int mi = 0; mi < MR; ++mi) a[mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, ks * 2 + lh));
-#pragma unroll
-            for (int ni = 0; ni < NR; ++ni) b[ni] = *(const bf16x8*)(Bs + kc_off((wn * NR + ni) * 32 + lr, ks * 2 + lh));
-#pragma unroll
-            for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NR; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int R = (wave * B_INSTR + i) * 8 + lrow;
+            voffB[i] = (int)(((long)(col_blk + R) * g.b_sj + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
         }
+        auto issue = [&](int k0, int buf) {
+            char* a_dst = lds + buf * STAGE + wave * A_INSTR * 1024;
+            char* b_dst = lds + buf * STAGE + A_BYTES + wave * B_INSTR * 1024;
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) glds16(rsA, a_dst + i * 1024, voffA[i], k0 * 2);
+#pragma unroll
+            for (int i = 0; i < B_INSTR; ++i) glds16(rsB, b_dst + i * 1024, voffB[i], k0 * 2);
+        };
+
+        // ring of NS stages, tiles are issued NS-1 ahead of their use (the previous tile's epilogue ended with a
+        // barrier, so the ring is free)
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < nk) issue(p * BK, p);
+
+        f32x16 acc[MR][NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // bias / relu-mask words of this wave's sub-tiles: their global-load latency hides under the main loop.
+        // (issued after the LDS-DMA groups so that the counted waits below still cover every DMA group)
+        EpiPrefetch<MR, NR> pf;
+        epilogue_prefetch<__bf16, EPI, MR, NR, VAR>(pf, g, batch, row_blk, col_blk, wm, wn, lane);
+
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // vmcnt counts in issue order (stores of the previous tile and the prefetch loads are older than or as old
+            // as the group being waited for, so waiting for the group also retires them)
+            if (kt == 0) STAMP(0);                                        // tile setup + issue
+            wait_groups<A_INSTR + B_INSTR>(min(NS - 2, nk - 1 - kt));   // this wave's loads of k-tile kt have landed
+            __builtin_amdgcn_s_barrier();                                 // ... everyone's; everyone finished k-tile kt-1
+            asm volatile("" ::: "memory");
+            if (kt == 0) STAMP(1);                                        // first k-tile landed (pipeline fill)
+            if (kt + NS - 1 < nk) {                                       // refill the stage read during k-tile kt-1
+                int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
+                issue((kt + NS - 1) * BK, nb);
+            }
+            const char* As = lds + buf * STAGE;
+            const char* Bs = As + A_BYTES;
+            buf = (buf + 1 == NS) ? 0 : buf + 1;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[MR], b[NR];
+#pragma unroll
+                for (int mi = 0; mi < MR; ++mi) a[mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, ks * 2 + lh));
+#pragma unroll
+                for (int ni = 0; ni < NR; ++ni) b[ni] = *(const bf16x8*)(Bs + kc_off((wn * NR + ni) * 32 + lr, ks * 2 + lh));
+#pragma unroll
+                for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NR; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        STAMP(2);               // main loop
+        __syncthreads();
+        STAMP(3);               // barrier after the main loop
+        // the BM x BNT bf16 output tile is assembled at the start of the (now dead) ring, column-sum scratch behind it
+        epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
+                                                     (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf);
+        STAMP(4);               // epilogue (math, staging, copy-out issue, column sums)
+        __syncthreads();        // the copy-out has read the staged tile: the ring may be refilled
+        STAMP(5);
     }
-    __syncthreads();
-    // the BM x BNT bf16 output tile is assembled at the start of the (now dead) ring, column-sum scratch behind it
-    epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
-                                                 (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf);
+#ifdef MRGAN_STAMPS
+    if (g.e.slab && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) ((unsigned long long*)g.e.slab)[(long)blockIdx.x * 8 + i] = st_[i];
+#endif
 }
 
 thread_local const char* g_last_kernel = "";
@@ -188,7 +213,10 @@ int launch_kc(const GemmArgs& g, hipStream_t s) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
         attr_done = true;
     }
-    dim3 grid(ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch);
+    // persistent blocks: at most as many as can be co-resident (LDS-limited) on the 256 CUs
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch;
+    const int per_cu = std::max(1, (160 * 1024) / LDS);
+    dim3 grid(std::min(tiles, 256 * per_cu));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, s, g);
     return 0;
 }
@@ -210,14 +238,18 @@ __device__ __forceinline__ bf16x8 ks_frag_swz(const char* tile, int fb, int ks, 
     return __builtin_bit_cast(bf16x8, tt);
 }
 
-template <int NS>
-__global__ __launch_bounds__(256) void gemm_bf16_ks_fast_kernel(const GemmArgs g) {
+template <int NS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_fast_kernel(const GemmArgs g) {
+    constexpr int NW = WM * WN;
+    constexpr int MR = 128 / WM / 32, NR = 128 / WN / 32;
     constexpr int T_BYTES = 64 * 256, STAGE = 2 * T_BYTES;
+    constexpr int T_INSTR = 16 / NW;                    // wave-instructions per wave per operand tile (4 k-rows x 256 B each)
+    static_assert(MR >= 1 && NR >= 1 && T_INSTR >= 1, "tile/wave layout");
     extern __shared__ __attribute__((aligned(16))) char lds[];        // NS * STAGE bytes
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int ntn = (g.N + 127) / 128, ntm = (g.M + 127) / 128;
     const int tidx = xcd_tile(blockIdx.x, ntn * ntm * g.splits);
     const int split = tidx / (ntn * ntm), rem = tidx - split * (ntn * ntm);
@@ -230,80 +262,78 @@ __global__ __launch_bounds__(256) void gemm_bf16_ks_fast_kernel(const GemmArgs g
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)((long)g.K * g.b_sk * 2), 0x00020000);
     // a wave-instruction covers 4 k-rows x 256 B; lane -> (k-row, swizzled source chunk)
     const int lrow = lane >> 4, lp = lane & 15;
-    int voffA[4], voffB[4];
+    int voffA[T_INSTR], voffB[T_INSTR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kr = (wave * 4 + i) * 4 + lrow;
+    for (int i = 0; i < T_INSTR; ++i) {
+        const int kr = (wave * T_INSTR + i) * 4 + lrow;
         const int c = lp ^ ((kr & 3) << 2);
         voffA[i] = (int)(((long)kr * g.a_sk + row_blk + c * 8) * 2);
         voffB[i] = (int)(((long)kr * g.b_sk + col_blk + c * 8) * 2);
     }
     auto issue = [&](int k0, int buf) {
-        char* a_dst = lds + buf * STAGE + wave * 4096;
+        char* a_dst = lds + buf * STAGE + wave * T_INSTR * 1024;
         char* b_dst = a_dst + T_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(rsA, a_dst + i * 1024, voffA[i], (int)((long)k0 * g.a_sk * 2));
+        for (int i = 0; i < T_INSTR; ++i) glds16(rsA, a_dst + i * 1024, voffA[i], (int)((long)k0 * g.a_sk * 2));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(rsB, b_dst + i * 1024, voffB[i], (int)((long)k0 * g.b_sk * 2));
+        for (int i = 0; i < T_INSTR; ++i) glds16(rsB, b_dst + i * 1024, voffB[i], (int)((long)k0 * g.b_sk * 2));
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MR][NR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NR; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (k_end - k_begin + BK - 1) / BK;
-    const bool do_load = !(g.e.ablate & 32), do_mma = !(g.e.ablate & 16);      // timing experiments
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
-        if (p < nk && do_load) issue(k_begin + p * BK, p);
+        if (p < nk) issue(k_begin + p * BK, p);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        wait_groups<8>(min(NS - 2, nk - 1 - kt));
+        wait_groups<2 * T_INSTR>(min(NS - 2, nk - 1 - kt));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + NS - 1 < nk && do_load) {
+        if (kt + NS - 1 < nk) {
             int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
             issue(k_begin + (kt + NS - 1) * BK, nb);
         }
         const char* As = lds + buf * STAGE;
         const char* Bs = As + T_BYTES;
         buf = (buf + 1 == NS) ? 0 : buf + 1;
-        if (!do_mma) continue;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[MR], b[NR];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = ks_frag_swz(As, (wm * 2 + mi) * 32, ks, lane);
+            for (int mi = 0; mi < MR; ++mi) a[mi] = ks_frag_swz(As, (wm * MR + mi) * 32, ks, lane);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = ks_frag_swz(Bs, (wn * 2 + ni) * 32, ks, lane);
+            for (int ni = 0; ni < NR; ++ni) b[ni] = ks_frag_swz(Bs, (wn * NR + ni) * 32, ks, lane);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NR; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     }
     __syncthreads();
-    epilogue<__bf16, EPI_SLAB, 2, 2, 2>(acc, g, 0, split, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BN);
+    epilogue<__bf16, EPI_SLAB, MR, NR, WM>(acc, g, 0, split, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BN);
 }
 
-template <int NS>
+template <int NS, int WM, int WN>
 int launch_ks_fast(const GemmArgs& g, hipStream_t s) {
-    static const std::string name = "gemm_bf16_ks_fast_kernel<" + std::to_string(NS) + ">";
+    static const std::string name = "gemm_bf16_ks_fast_kernel<" + std::to_string(NS) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ">";
     g_last_kernel = name.c_str();
     constexpr int STAGE = 2 * 64 * 256;
     static bool attr_done = false;
-    auto kern = gemm_bf16_ks_fast_kernel<NS>;
+    auto kern = gemm_bf16_ks_fast_kernel<NS, WM, WN>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE) != hipSuccess) return -2;
         attr_done = true;
     }
     dim3 grid(ceil_div(g.N, 128) * ceil_div(g.M, 128) * g.splits);
-    hipLaunchKernelGGL(kern, grid, dim3(256), NS * STAGE, s, g);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), NS * STAGE, s, g);
     return 0;
 }
 
@@ -466,8 +496,9 @@ int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kna
                              (g.seg_rows >= g.seg_stride || g.K <= g.seg_rows) &&
                              (long)g.K * g.a_sk * 2 < (1L << 31) && (long)g.K * g.b_sk * 2 < (1L << 31);
         if (dense_k) {
-            static const int ns = env_int("MRGAN_KS_NS", 3);
-            r = ns == 2 ? launch_ks_fast<2>(g, s) : ns == 3 ? launch_ks_fast<3>(g, s) : launch_ks_fast<4>(g, s);
+            // MRGAN_KS_CFG: 0 = 4 waves (64x64 each), 3-stage ring ; 1 = 8 waves (64x32 each), 3 stages ; 2 = 8 waves, 4 stages
+            static const int cfg = env_int("MRGAN_KS_CFG", 1);
+            r = cfg == 0 ? launch_ks_fast<3, 2, 2>(g, s) : cfg == 1 ? launch_ks_fast<3, 2, 4>(g, s) : launch_ks_fast<4, 2, 4>(g, s);
         } else {
             dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, 128), g.nbatch * g.splits);
             hipLaunchKernelGGL(gemm_bf16_ks_kernel, grid, dim3(256), 0, s, g);

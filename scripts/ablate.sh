@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-category kernel time of one bench step under each ablation bit (eager launches, hipEvent timing)
-for a in ${ABLATE_LIST:-0 1 8 9 2 4 6}; do
+for a in ${ABLATE_LIST:-0 2 4 6}; do
   echo "ablate=$a"; python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --ablate $a 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); km=d['roofline']['step']['kernel_ms']

@@ -8,6 +8,8 @@ from mr_gan_amd import engine as E
 B = 4096
 SHAPES = [  # (name, op, m, n, k, nbatch, splits)
     ("fwd D1 3Bx512->1024", 0, B, 1024, 512, 3, 1),
+    ("fwd D1 relu+mask only", 3, B, 1024, 512, 3, 1),
+    ("fwd D1 plain relu", 4, B, 1024, 512, 3, 1),
     ("fwd D2 3Bx1024->512", 0, B, 512, 1024, 3, 1),
     ("fwd D3 3Bx512->256", 0, B, 256, 512, 3, 1),
     ("fwd D4 3Bx256->256", 0, B, 256, 256, 3, 1),
