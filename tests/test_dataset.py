@@ -1,0 +1,56 @@
+"""dataset() / log-mel front end on a synthetic MREO-format pickle.
+The real dataset is a download (README.md:7-11) and the reference's librosa is absent: parity unpinned; these tests pin
+the file format handling (processdata.py:23-34, :91; mr_gan.py:32-62) and the basic properties of the mel front end."""
+import os
+import pickle
+
+import numpy as np
+
+from mr_gan_amd import dataset
+from mr_gan_amd.data import MATERIALS
+from mr_gan_amd.melspec import log_melspectrogram, mel_filterbank
+
+
+def _write_fake_mreo(tmp, ft=4, cm=0.2, objects=2, trials=3):
+    rng = np.random.default_rng(0)
+    for m, material in enumerate(MATERIALS):
+        allData = {}
+        for o in range(objects):
+            d = {k: [] for k in ('forceTime', 'force0', 'force1', 'pressureTime', 'pressure0', 'pressure1',
+                                 'temperatureTime', 'temperature', 'contactTime', 'contact')}
+            for t in range(trials):
+                n = int(100 * ft)
+                d['force0'].append((rng.standard_normal(n) + 10 * m).tolist())
+                d['force1'].append((rng.standard_normal(n) + 20 * m).tolist())
+                d['temperature'].append((rng.standard_normal(n) + 30 * m).tolist())
+                d['contact'].append(rng.standard_normal(int(48000 * cm)).tolist())
+            allData['%s_obj%d' % (material, o)] = d
+        with open(os.path.join(tmp, 'processed_0.1sbefore_%s_times_%.2f_%.2f.pkl' % (material, ft, cm)), 'wb') as f:
+            pickle.dump(allData, f, 2)          # protocol 2 = what Python-2 cPickle.HIGHEST_PROTOCOL wrote
+
+
+def test_dataset_modalities_and_order(tmp_path):
+    _write_fake_mreo(str(tmp_path))
+    mel = 128 * 19
+    want = {0: 800, 1: 400, 2: 1200, 3: mel, 4: 400 + mel, 5: 1200 + mel, 6: 800 + mel}
+    for mod, d in want.items():
+        X, y = dataset(modalities=mod, data_dir=str(tmp_path))
+        assert X.shape == (6 * 2 * 3, d) and y.shape == (36,)
+        assert list(np.unique(y)) == list(range(6))
+    X, y = dataset(modalities=2, data_dir=str(tmp_path))      # temperature | force0 | force1 (mr_gan.py:54)
+    r = X[y == 3][0]
+    assert abs(r[:400].mean() - 90) < 1 and abs(r[400:800].mean() - 30) < 1 and abs(r[800:].mean() - 60) < 1
+    objs = dataset(modalities=0, leaveObjectOut=True, data_dir=str(tmp_path))
+    assert len(objs) == 12 and np.array(objs['glass_obj1']['x']).shape == (3, 800)
+
+
+def test_log_mel_properties():
+    sr = 48000
+    t = np.arange(9600) / sr
+    S = log_melspectrogram(np.sin(2 * np.pi * 3000 * t), sr=sr)
+    assert S.shape == (128, 19)                                 # 1 + 9600 // 512 frames
+    assert S.max() == 0.0 and S.min() >= -80.0
+    fb = mel_filterbank(sr, 2048)
+    centre = np.argmax(fb[:, int(round(3000 / (sr / 2048)))])
+    assert abs(int(np.argmax(S.mean(axis=1))) - centre) <= 1    # energy lands in the 3 kHz band
+    assert np.all(fb >= 0) and fb.shape == (128, 1025)
