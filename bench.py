@@ -229,9 +229,17 @@ def main():
     gemm_ms = sum(v[0] for v in gemms.values()) / P
     gemm_flops = sum(v[2] for v in gemms.values()) / P
     all_ms = sum(v[0] for v in prof.values()) / P
+    # HBM bytes per launch of that kernel from the committed PMC summary (scripts/traffic.sh; separate --pmc passes,
+    # gfx950 FETCH_SIZE correction applied there); null if the summary has no row for it
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world == 1 and os.path.exists(tfile):
+        row = json.load(open(tfile)).get(dom)
+        if row:
+            traffic = {"hbm_bytes_per_launch": round(row["hbm_bytes_per_launch"]), "source": "profiles/r01_traffic.json"}
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-        "traffic": None,
+        "traffic": traffic,
         "kernel": dom, "launches_per_step": dom_launches / P,
         "avg_launch_us": round(1e6 * per_launch_s, 2), "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3),
         "all_gemm_kernels": {"achieved": round(gemm_flops / (1e-3 * gemm_ms) / 1e12, 2), "ms_per_step": round(gemm_ms, 4),
