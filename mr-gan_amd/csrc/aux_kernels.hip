@@ -99,46 +99,51 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
 }
 
 // =========================================================================================
-// BatchNorm forward with batch statistics (biased variance, eps inside the sqrt).
-// Block = 256 columns x 64 rows.  Each thread first folds the per-row-tile partial sums of one
-// column into (scale, shift) in LDS, then the block streams its rows 16 bytes per lane.
+// Column-statistic kernels (BatchNorm forward / backward, feature matching).
+// Block = CB (64) columns x RB (64) rows, 256 threads.  Prologue: the per-64-row partial sums of the block's
+// columns are folded by 16 "partial lanes" (thread = 4 columns x every 16th partial row, 16-byte loads) and
+// combined through LDS; body: thread = 8 columns (16 B of bf16) x every 32nd row.  ld/64 x rows/64 blocks keep
+// >= 256 blocks in flight for the shapes of this model.
 // =========================================================================================
-constexpr int RB = 64;      // rows per block of the column-statistic kernels
+constexpr int RB = 64, CB = 64;
 
-// Block-cooperative sum of `npart` partial rows for 256 consecutive columns starting at col0:
-// thread = (column quad t&63, partial lane t>>6); each lane folds every 4th partial row with 16-byte
-// loads, LDS combines the four lanes.  Result: out[c] for c in [0,256) valid after the barrier.
-__device__ __forceinline__ void fold_partials(const float* part, int npart, int ldcs, int col0, int ncols, float (*scr)[256], float* out) {
-    const int t = threadIdx.x, cq = (t & 63) * 4, pl = t >> 6;
+__device__ __forceinline__ void fold_partials(const float* part, int npart, int ldcs, int col0, int ncols, float (*scr)[CB], float* out) {
+    const int t = threadIdx.x, cq = (t & 15) * 4, pl = t >> 4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (col0 + cq < ncols) {
         int p = pl;
-        for (; p + 4 < npart; p += 8) {
+        for (; p + 16 < npart; p += 32) {
             s0 += *(const f32x4*)(part + (long)p * ldcs + col0 + cq);
-            s1 += *(const f32x4*)(part + (long)(p + 4) * ldcs + col0 + cq);
+            s1 += *(const f32x4*)(part + (long)(p + 16) * ldcs + col0 + cq);
         }
-        for (; p < npart; p += 4) s0 += *(const f32x4*)(part + (long)p * ldcs + col0 + cq);
+        for (; p < npart; p += 16) s0 += *(const f32x4*)(part + (long)p * ldcs + col0 + cq);
     }
     s0 += s1;
     *(f32x4*)(&scr[pl][cq]) = s0;
     __syncthreads();
-    out[t] = (scr[0][t] + scr[1][t]) + (scr[2][t] + scr[3][t]);
+    if (t < CB) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += scr[k][t];
+        out[t] = s;
+    }
     __syncthreads();
 }
+
+// BatchNorm forward with batch statistics (biased variance, eps inside the sqrt; mr_gan.py:112)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
-    __shared__ float sc[256], sh[256];
-    __shared__ float scr[4][256], f1[256], f2[256];
-    const int t = threadIdx.x;
-    fold_partials(a.cs1, a.npart, a.ldcs, blockIdx.x * 256, a.ld, scr, f1);
-    fold_partials(a.cs2, a.npart, a.ldcs, blockIdx.x * 256, a.ld, scr, f2);
-    {
-        const int col = blockIdx.x * 256 + t;
+    __shared__ float sc[CB], sh[CB];
+    __shared__ float scr[16][CB], f1[CB], f2[CB];
+    const int t = threadIdx.x, col0 = blockIdx.x * CB;
+    fold_partials(a.cs1, a.npart, a.ldcs, col0, a.ld, scr, f1);
+    fold_partials(a.cs2, a.npart, a.ldcs, col0, a.ld, scr, f2);
+    if (t < CB) {
+        const int col = col0 + t;
         float scale = 0.f, shift = 0.f;
         if (col < a.ld) {
-            const float s1 = f1[t], s2 = f2[t];
-            const float mean = s1 / a.count;
-            const float var = fmaxf(s2 / a.count - mean * mean, 0.f);
+            const float mean = f1[t] / a.count;
+            const float var = fmaxf(f2[t] / a.count - mean * mean, 0.f);
             const float rstd = 1.0f / sqrtf(var + a.eps);
             if (col < a.cols) { scale = a.gamma[col] * rstd; shift = a.beta[col] - mean * scale; }
             if (blockIdx.y == 0) { a.mu[col] = mean; a.rstd[col] = rstd; }
@@ -146,12 +151,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
         sc[t] = scale; sh[t] = shift;
     }
     __syncthreads();
-    const int cg = t & 31, rl = t >> 5, c0 = blockIdx.x * 256 + cg * 8;
+    const int cg = t & 7, rl = t >> 3, c0 = col0 + cg * 8;
     if (c0 >= a.ld) return;
     const T* h = (const T*)a.h;
     T* out = (T*)a.out;
     const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
-    for (int r = blockIdx.y * RB + rl; r < r1; r += 8) {
+    for (int r = blockIdx.y * RB + rl; r < r1; r += 32) {
         float v[8];
         load8<T>(h + (long)r * a.ld + c0, v);
 #pragma unroll
@@ -164,20 +169,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
 // (h = softplus(pre)  =>  sigmoid(pre) = 1 - exp(-h)); emits the bias-gradient partial sums.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
-    __shared__ float cA[256], cB[256], cM[256], cR[256];      // k = gamma*rstd/count ; dbeta ; mu ; rstd
-    __shared__ float cG[256];                                 // dgamma
-    __shared__ float red[8][256];
-    const int t = threadIdx.x;
-    fold_partials(a.cs1, a.npart, a.ldcs, blockIdx.x * 256, a.ld, red, cB);
-    fold_partials(a.cs2, a.npart, a.ldcs, blockIdx.x * 256, a.ld, red, cG);
-    {
-        const int col = blockIdx.x * 256 + t;
+    __shared__ float cA[CB], cB[CB], cM[CB], cR[CB], cG[CB];   // gamma*rstd/count ; dbeta ; mu ; rstd ; dgamma
+    __shared__ float red[32][CB];
+    const int t = threadIdx.x, col0 = blockIdx.x * CB;
+    fold_partials(a.cs1, a.npart, a.ldcs, col0, a.ld, red, cB);
+    fold_partials(a.cs2, a.npart, a.ldcs, col0, a.ld, red, cG);
+    if (t < CB) {
+        const int col = col0 + t;
         float g = 0.f, mu = 0.f, rs = 0.f;
         if (col < a.cols) { g = a.gamma[col]; mu = a.mu[col]; rs = a.rstd[col]; }
         cA[t] = g * rs / a.count; cM[t] = mu; cR[t] = rs;
     }
     __syncthreads();
-    const int cg = t & 31, rl = t >> 5, c0 = blockIdx.x * 256 + cg * 8;
+    const int cg = t & 7, rl = t >> 3, c0 = col0 + cg * 8;
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
         const T* h = (const T*)a.h;
         T* dpre = (T*)a.dpre;
         const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
-        for (int r = blockIdx.y * RB + rl; r < r1; r += 8) {
+        for (int r = blockIdx.y * RB + rl; r < r1; r += 32) {
             float hv[8], d[8], o[8];
             load8<T>(h + (long)r * a.ld + c0, hv);
             load8<T>(dy + (long)r * a.ld + c0, d);
@@ -204,12 +208,11 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) red[rl][cg * 8 + i] = acc[i];
     __syncthreads();
-    const int col = blockIdx.x * 256 + t;
-    if (col < a.ld) {
+    if (t < CB && col0 + t < a.ld) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][t];
-        a.db_part[(long)blockIdx.y * a.ld + col] = s;
+        for (int k = 0; k < 32; ++k) s += red[k][t];
+        a.db_part[(long)blockIdx.y * a.ld + col0 + t] = s;
     }
 }
 
@@ -387,36 +390,46 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* src, 
 // =========================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
-    __shared__ float gj_lds[256];
-    __shared__ float red[4];
-    __shared__ float scr[4][256], sf[256], sr[256];
-    const int t = threadIdx.x;
-    fold_partials(a.cs, a.npart_fake, a.ldcs, 0, a.feat, scr, sf);
-    fold_partials(a.cs + (long)a.npart_fake * a.ldcs, a.npart_real, a.ldcs, 0, a.feat, scr, sr);
-    float diff = 0.f;
-    if (t < a.feat_valid) diff = (sf[t] - sr[t]) / a.count;
-    gj_lds[t] = a.grad_scale * 2.0f / ((float)a.feat_valid * a.count) * diff;
-    if (blockIdx.y == 0) {
-        const float s = wave_sum(diff * diff);
-        if ((t & 63) == 0) red[t >> 6] = s;
+    __shared__ float gj_lds[CB];
+    __shared__ float scr[16][CB], sf[CB], sr[CB], red[4];
+    const int t = threadIdx.x, col0 = blockIdx.x * CB;
+    const float* cs_real = a.cs + (long)a.npart_fake * a.ldcs;
+    fold_partials(a.cs, a.npart_fake, a.ldcs, col0, a.feat, scr, sf);
+    fold_partials(cs_real, a.npart_real, a.ldcs, col0, a.feat, scr, sr);
+    if (t < CB) {
+        const float diff = (col0 + t < a.feat_valid) ? (sf[t] - sr[t]) / a.count : 0.f;
+        gj_lds[t] = a.grad_scale * 2.0f / ((float)a.feat_valid * a.count) * diff;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        // the loss scalar needs every column: this one block folds the other column groups as well (fixed order)
+        float tot = 0.f;
+        for (int c0 = 0; c0 < a.feat; c0 += CB) {
+            __syncthreads();
+            fold_partials(a.cs, a.npart_fake, a.ldcs, c0, a.feat, scr, sf);
+            fold_partials(cs_real, a.npart_real, a.ldcs, c0, a.feat, scr, sr);
+            float d2 = 0.f;
+            if (t < CB && c0 + t < a.feat_valid) { const float d = (sf[t] - sr[t]) / a.count; d2 = d * d; }
+            d2 = wave_sum(d2);
+            if (t == 0) tot += d2;                       // columns live in wave 0 (t < 64)
+        }
+        if (t == 0) {
+            const float loss = tot / (float)a.feat_valid;
+            if (a.loss_out) *a.loss_out = loss;
+            if (a.accum) *a.accum += loss;
+        }
     }
     __syncthreads();
-    if (blockIdx.y == 0 && t == 0) {
-        const float loss = (red[0] + red[1] + red[2] + red[3]) / (float)a.feat_valid;
-        if (a.loss_out) *a.loss_out = loss;
-        if (a.accum) *a.accum += loss;
-    }
-    const int cg = t & 31, rl = t >> 5, c0 = cg * 8;
+    const int cg = t & 7, rl = t >> 3, c0 = col0 + cg * 8;
     if (c0 >= a.feat) return;
     T* dpre = (T*)a.dpre;
     const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
-    for (int r = blockIdx.y * RB + rl; r < r1; r += 8) {
+    for (int r = blockIdx.y * RB + rl; r < r1; r += 32) {
         // lane-native mask layout (gemm.h): per (32-row block, column) two u16 words, one per lane half
         const int rr = r & 31, half = (rr >> 2) & 1, bit = (rr & 3) | ((rr >> 3) << 2);
         const uint32_t* mp = (const uint32_t*)(a.mask + ((long)(r >> 5) * a.ldm + c0) * 2);
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (((mp[i] >> (16 * half)) >> bit) & 1u) ? gj_lds[c0 + i] : 0.f;
+        for (int i = 0; i < 8; ++i) v[i] = (((mp[i] >> (16 * half)) >> bit) & 1u) ? gj_lds[cg * 8 + i] : 0.f;
         store8<T>(dpre + (long)r * a.ldd + c0, v);
     }
 }
@@ -567,7 +580,7 @@ int launch_stage(int bf16, const StageArgs& a, hipStream_t s) {
 }
 
 int launch_bn_apply(int bf16, const BnApplyArgs& a, hipStream_t s) {
-    dim3 grid(ceil_div(a.ld, 256), ceil_div(a.rows, RB));
+    dim3 grid(ceil_div(a.ld, CB), ceil_div(a.rows, RB));
     LAUNCH_T(bn_apply_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }
@@ -575,7 +588,7 @@ int launch_bn_apply(int bf16, const BnApplyArgs& a, hipStream_t s) {
 int stat_row_blocks(int rows) { return ceil_div(rows, RB); }
 
 int launch_bn_bwd(int bf16, const BnBwdArgs& a, hipStream_t s) {
-    dim3 grid(ceil_div(a.ld, 256), ceil_div(a.rows, RB));
+    dim3 grid(ceil_div(a.ld, CB), ceil_div(a.rows, RB));
     LAUNCH_T(bn_bwd_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }
@@ -602,8 +615,8 @@ int launch_reduce_partials(const float* src, int nsrc, long stride, int n, int n
 }
 
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s) {
-    if (a.feat > 256 || (a.feat % 8) != 0) return -3;
-    dim3 grid(1, ceil_div(a.rows, RB));
+    if ((a.feat % 8) != 0) return -3;
+    dim3 grid(ceil_div(a.feat, CB), ceil_div(a.rows, RB));
     LAUNCH_T(fm_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }
