@@ -5,7 +5,7 @@
 namespace mrgan {
 
 constexpr int KMAX = 8;            // classes are padded to 8 logits (reference: 6 materials, mr_gan.py:80)
-constexpr int HEAD_ROWS = 64;      // rows per loss-head block
+constexpr int HEAD_ROWS = 32;      // rows per loss-head block
 
 // ---- staging: rows of the (scaled) data matrix -> noisy discriminator input; z -> generator input ----
 struct StageSeg {

@@ -219,14 +219,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
 // =========================================================================================
 // loss head: logits = f W6 + b6 ; labeled / unlabeled / fake losses of mr_gan.py:146-149 ; train error
 // :161 ; closed-form dlogits ; dW6, db6 ; and dL/d(pre5) = (dlogits W6^T) * [f > 0].
-// One block = 64 rows of one segment.  LDS: f tile as fp32 [64][feat+4], W6 [feat][8], dlogits [64][8].
+// One block = HEAD_ROWS rows of one segment.  LDS: f tile as fp32 [HR][feat+8], W6 [feat][8], dlogits [HR][8].
 // Per-block partial gradients go to part[blk][...]; reduce_partials_kernel folds them to <= 8 slabs.
 // =========================================================================================
 constexpr int HR = HEAD_ROWS;
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float hl[];
-    const int LDF = a.feat + 4;
+    const int LDF = a.feat + 8;
     float* f_lds = hl;                         // [HR][LDF]
     float* w_lds = f_lds + HR * LDF;           // [feat][KMAX]
     float* dl_lds = w_lds + a.feat * KMAX;     // [HR][KMAX]
@@ -255,13 +255,14 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     }
     __syncthreads();
 
-    // ---- logits: 4 lanes per row, each over an interleaved quarter of the features ----
-    const int r = t >> 2, part = t & 3;
+    // ---- logits: LPR lanes per row, each over an interleaved slice of the features ----
+    constexpr int LPR = 256 / HR;
+    const int r = t / LPR, part = t % LPR;
     float l[KMAX];
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) l[c] = 0.f;
-    for (int kk = 0; kk < a.feat / 4; ++kk) {
-        const int k = kk * 4 + part;
+    for (int kk = 0; kk < a.feat / LPR; ++kk) {
+        const int k = kk * LPR + part;
         const float fv = f_lds[r * LDF + k];
         const f32x4 w0 = *(const f32x4*)(w_lds + k * KMAX), w1 = *(const f32x4*)(w_lds + k * KMAX + 4);
 #pragma unroll
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
-        l[c] += __shfl_xor(l[c], 1, 64);
-        l[c] += __shfl_xor(l[c], 2, 64);
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) l[c] += __shfl_xor(l[c], m, 64);
     }
     const int row = row_blk + r;
     const bool rowvalid = row < a.rows;
@@ -391,32 +392,44 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* src, 
 template <typename T>
 __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
     __shared__ float gj_lds[CB];
-    __shared__ float scr[16][CB], sf[CB], sr[CB], red[4];
+    __shared__ float scr[16][CB], sf[CB], sr[CB];
     const int t = threadIdx.x, col0 = blockIdx.x * CB;
     const float* cs_real = a.cs + (long)a.npart_fake * a.ldcs;
-    fold_partials(a.cs, a.npart_fake, a.ldcs, col0, a.feat, scr, sf);
-    fold_partials(cs_real, a.npart_real, a.ldcs, col0, a.feat, scr, sr);
-    if (t < CB) {
-        const float diff = (col0 + t < a.feat_valid) ? (sf[t] - sr[t]) / a.count : 0.f;
-        gj_lds[t] = a.grad_scale * 2.0f / ((float)a.feat_valid * a.count) * diff;
-    }
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        // the loss scalar needs every column: this one block folds the other column groups as well (fixed order)
+    if (blockIdx.y == gridDim.y - 1) {
+        // the extra block row: block x == 0 produces the loss scalar, which needs every column.  Thread = 4 columns x
+        // every 4th partial row, all loads independent, so this block is no slower than the row blocks.
+        if (blockIdx.x != 0) return;
+        float* dsc = &scr[0][0];                          // [4][256] view of the 16 x 64 scratch
         float tot = 0.f;
-        for (int c0 = 0; c0 < a.feat; c0 += CB) {
+        const int q = (t & 63) * 4, pl = t >> 6;
+        for (int c0 = 0; c0 < a.feat; c0 += 256) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (c0 + q < a.feat) {
+                for (int p = pl; p < a.npart_fake; p += 4) d += *(const f32x4*)(a.cs + (long)p * a.ldcs + c0 + q);
+                for (int p = pl; p < a.npart_real; p += 4) d -= *(const f32x4*)(cs_real + (long)p * a.ldcs + c0 + q);
+            }
             __syncthreads();
-            fold_partials(a.cs, a.npart_fake, a.ldcs, c0, a.feat, scr, sf);
-            fold_partials(cs_real, a.npart_real, a.ldcs, c0, a.feat, scr, sr);
-            float d2 = 0.f;
-            if (t < CB && c0 + t < a.feat_valid) { const float d = (sf[t] - sr[t]) / a.count; d2 = d * d; }
-            d2 = wave_sum(d2);
-            if (t == 0) tot += d2;                       // columns live in wave 0 (t < 64)
+            *(f32x4*)(dsc + pl * 256 + q) = d;
+            __syncthreads();
+            float v = 0.f;
+            if (c0 + t < a.feat_valid) { v = (dsc[t] + dsc[256 + t] + dsc[512 + t] + dsc[768 + t]) / a.count; v *= v; }
+            v = wave_sum(v);
+            if ((t & 63) == 0) sf[t >> 6] = v;
+            __syncthreads();
+            if (t == 0) tot += sf[0] + sf[1] + sf[2] + sf[3];
         }
         if (t == 0) {
             const float loss = tot / (float)a.feat_valid;
             if (a.loss_out) *a.loss_out = loss;
             if (a.accum) *a.accum += loss;
         }
+        return;
+    }
+    fold_partials(a.cs, a.npart_fake, a.ldcs, col0, a.feat, scr, sf);
+    fold_partials(cs_real, a.npart_real, a.ldcs, col0, a.feat, scr, sr);
+    if (t < CB) {
+        const float diff = (col0 + t < a.feat_valid) ? (sf[t] - sr[t]) / a.count : 0.f;
+        gj_lds[t] = a.grad_scale * 2.0f / ((float)a.feat_valid * a.count) * diff;
     }
     __syncthreads();
     const int cg = t & 7, rl = t >> 3, c0 = col0 + cg * 8;
@@ -603,7 +616,7 @@ int init_kernel_attributes() {
 
 int launch_head(int bf16, const HeadArgs& a, hipStream_t s) {
     if (a.feat > 256 || (a.feat % 8) != 0 || a.classes > KMAX) return -3;
-    const size_t smem = sizeof(float) * ((size_t)HR * (a.feat + 4) + (size_t)a.feat * KMAX + HR * KMAX + 16);
+    const size_t smem = sizeof(float) * ((size_t)HR * (a.feat + 8) + (size_t)a.feat * KMAX + HR * KMAX + 16);
     dim3 grid(ceil_div(a.rows, HR), a.nseg);
     LAUNCH_T(head_kernel, grid, dim3(256), smem, s, a);
     RET_LAUNCH;
@@ -616,7 +629,7 @@ int launch_reduce_partials(const float* src, int nsrc, long stride, int n, int n
 
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s) {
     if ((a.feat % 8) != 0) return -3;
-    dim3 grid(ceil_div(a.feat, CB), ceil_div(a.rows, RB));
+    dim3 grid(ceil_div(a.feat, CB), ceil_div(a.rows, RB) + 1);      // + the loss block row
     LAUNCH_T(fm_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }
