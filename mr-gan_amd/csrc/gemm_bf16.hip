@@ -166,18 +166,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
             const char* As = lds + buf * STAGE;
             const char* Bs = As + A_BYTES;
             buf = (buf + 1 == NS) ? 0 : buf + 1;
+            // fragments of KG k-steps are fetched as one batch ahead of their MFMAs: the LDS latency is paid once per
+            // batch (counted lgkmcnt waits) instead of once per MFMA
+            constexpr int KG = (MR + NR <= 4) ? 4 : 2;
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 a[MR], b[NR];
+            for (int kg = 0; kg < BK / 16; kg += KG) {
+                bf16x8 a[KG][MR], b[KG][NR];
 #pragma unroll
-                for (int mi = 0; mi < MR; ++mi) a[mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, ks * 2 + lh));
+                for (int kk = 0; kk < KG; ++kk) {
 #pragma unroll
-                for (int ni = 0; ni < NR; ++ni) b[ni] = *(const bf16x8*)(Bs + kc_off((wn * NR + ni) * 32 + lr, ks * 2 + lh));
+                    for (int mi = 0; mi < MR; ++mi) a[kk][mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, (kg + kk) * 2 + lh));
 #pragma unroll
-                for (int mi = 0; mi < MR; ++mi)
+                    for (int ni = 0; ni < NR; ++ni) b[kk][ni] = *(const bf16x8*)(Bs + kc_off((wn * NR + ni) * 32 + lr, (kg + kk) * 2 + lh));
+                }
+                __builtin_amdgcn_sched_barrier(0);       // keep the scheduler from re-serialising read -> wait -> MFMA
 #pragma unroll
-                    for (int ni = 0; ni < NR; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                    for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NR; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][mi], b[kk][ni], acc[mi][ni], 0, 0, 0);
             }
         }
         STAMP(2);               // main loop
