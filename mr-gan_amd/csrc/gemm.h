@@ -65,7 +65,17 @@ template <int MR, int NR>
 struct EpiPrefetch {
     float bias[NR];
     uint32_t mbits[MR][NR];
+    uint32_t iter;               // DevState::iter for the noise key (FWD with noise)
 };
+
+// does this DX launch read e.h per element?  (softplus derivative, or the sum of dy * xhat for BatchNorm backward)
+template <int VAR>
+__device__ __host__ __forceinline__ bool dx_needs_h(const Epi& e) {
+    if constexpr ((VAR & VAR_DYN) != 0) return e.h && (e.act == ACT_SOFTPLUS || e.cs_mode == CS_SUM_XHAT);
+    else if constexpr ((VAR & VAR_ACT_MASK) == ACT_SOFTPLUS) return true;
+    else if constexpr ((VAR & VAR_ACT_MASK) == ACT_LINEAR) return e.cs_mode == CS_SUM_XHAT;
+    else return false;
+}
 
 template <typename T, int EPI, int MR, int NR, int VAR>
 __device__ __forceinline__ void epilogue_prefetch(EpiPrefetch<MR, NR>& pf, const GemmArgs& g, int batch, int row_blk, int col_blk,
@@ -73,6 +83,8 @@ __device__ __forceinline__ void epilogue_prefetch(EpiPrefetch<MR, NR>& pf, const
     const Epi& e = g.e;
     const int lc = lane & 31, lh = lane >> 5;
     const int act = (VAR & 64) ? e.act : (VAR & 3);
+    pf.iter = 0u;
+    if constexpr (EPI == EPI_FWD && ((VAR & VAR_DYN) || (VAR & VAR_NOISE))) { if (e.st) pf.iter = e.st->iter; }
 #pragma unroll
     for (int ni = 0; ni < NR; ++ni) {
         const int col = col_blk + (wn * NR + ni) * 32 + lc;
@@ -99,7 +111,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                                          int tile_m, int row_blk, int col_blk, int wm, int wn, int lane,
                                          float* lds /* >= 2*WM*bn floats of scratch, disjoint from `tile` */,
                                          int bn /* block tile width */, T* tile = nullptr,
-                                         const EpiPrefetch<MR, NR>* pf = nullptr) {
+                                         const EpiPrefetch<MR, NR>* pf = nullptr,
+                                         const T* htile = nullptr /* STAGED: LDS copy [BM][bn] of the block's tile of e.h */) {
     const Epi& e = g.e;
     const int lc = lane & 31, lh = lane >> 5;
     const int M = g.M;
@@ -132,7 +145,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         const T* hprev = e.h ? (const T*)e.h + (long)batch * e.h_bs : nullptr;
         const bool noisy = EPI == EPI_FWD && (DYN ? e.sigma > 0.f : (VAR & VAR_NOISE) != 0);
         uint32_t nkey = 0;
-        if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)batch, e.st ? e.st->iter : 0u);
+        if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)batch, pf ? pf->iter : (e.st ? e.st->iter : 0u));
 
 #pragma unroll
         for (int ni = 0; ni < NR; ++ni) {
@@ -181,7 +194,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             if (act == ACT_RELU)        // all-ones / zero from the mask bit, applied to the float's bits
                                 v = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & (uint32_t)(-(int)((mbits >> r) & 1u)));
                             else if (act == ACT_SOFTPLUS) {
-                                const float hv = (row < M && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
+                                float hv;
+                                if constexpr (STAGED) hv = (row < M && colin) ? Elem<T>::to_f32(htile[(row - row_blk) * bn + (col - col_blk)]) : 0.f;
+                                else hv = (row < M && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
                                 // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
                                 v *= fast_math ? one_minus_exp_neg_fast(hv) : -expm1f(-hv);
                             }
@@ -232,7 +247,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                                 const int row = rsub + (r & 3) + 8 * (r >> 2);
                                 const bool ok = row < M;
                                 const float v = ok ? acc[mi][ni][r] : 0.f;
-                                const float hv = (ok && cok) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : mu;
+                                float hv;
+                                if constexpr (STAGED) hv = (ok && cok) ? Elem<T>::to_f32(htile[(row - row_blk) * bn + (col - col_blk)]) : mu;
+                                else hv = (ok && cok) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : mu;
                                 s1 += v; s2 = fmaf(v * (hv - mu), rstd, s2);
                             }
                         } else {

@@ -193,8 +193,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
         __syncthreads();
         STAMP(3);               // barrier after the main loop
         // the BM x BNT bf16 output tile is assembled at the start of the (now dead) ring, column-sum scratch behind it
+        const __bf16* htile = nullptr;
+        if constexpr (EPI == EPI_DX) {
+            // DX epilogues that read e.h element-wise (one column per lane, rows strided) get the block's tile of h
+            // copied into LDS with 16-byte LDS-DMA loads first: one round trip instead of one per element.
+            if (dx_needs_h<VAR>(g.e)) {
+                char* hdst = lds + BM * BNT * 2 + 4 * WM * BNT * 4;
+                const __bf16* hb = (const __bf16*)g.e.h + (long)batch * g.e.h_bs;
+                const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, (int)((long)g.M * g.e.ldh * 2), 0x00020000);
+                constexpr int RPI = 1024 / (BNT * 2);              // tile rows per wave-instruction
+                constexpr int LPR = 64 / RPI;                      // lanes per row
+#pragma unroll
+                for (int i = 0; i < BM / RPI / NW; ++i) {
+                    const int R = (wave * (BM / RPI / NW) + i) * RPI + lane / LPR;
+                    const int voff = (int)(((long)(row_blk + R) * g.e.ldh + col_blk) * 2) + (lane % LPR) * 16;
+                    glds16(rsH, hdst + (wave * (BM / RPI / NW) + i) * 1024, voff, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                htile = (const __bf16*)hdst;
+            }
+        }
         epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
-                                                     (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf);
+                                                     (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf, htile);
         STAMP(4);               // epilogue (math, staging, copy-out issue, column sums)
         __syncthreads();        // the copy-out has read the staged tile: the ring may be refilled
         STAMP(5);
@@ -214,7 +235,9 @@ int launch_kc(const GemmArgs& g, hipStream_t s) {
                                     std::to_string(NS) + ", " + std::to_string(VAR) + ">";
     g_last_kernel = name.c_str();
     constexpr int STAGE = BM * 128 + BNT * 128;
-    constexpr int OUT = BM * BNT * 2 + 4 * WM * BNT * 4;           // staged output tile + column-sum scratch
+    // staged output tile + column-sum scratch (+ the tile of e.h for the DX epilogues that read it)
+    constexpr int OUT = BM * BNT * 2 + 4 * WM * BNT * 4 + ((EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU) ? BM * BNT * 2 : 0);
+    static_assert(OUT <= 160 * 1024, "LDS budget");
     constexpr int LDS = NS * STAGE > OUT ? NS * STAGE : OUT;
     static bool attr_done = false;
     auto kern = gemm_bf16_kc_kernel<EPI, BM, BNT, WM, WN, NS, VAR>;
@@ -312,18 +335,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_fast_kernel(const G
         const char* As = lds + buf * STAGE;
         const char* Bs = As + T_BYTES;
         buf = (buf + 1 == NS) ? 0 : buf + 1;
+        constexpr int KG = (MR + NR <= 4) ? 4 : 2;       // fragment batches, as in the KC kernel
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[MR], b[NR];
+        for (int kg = 0; kg < BK / 16; kg += KG) {
+            bf16x8 a[KG][MR], b[KG][NR];
 #pragma unroll
-            for (int mi = 0; mi < MR; ++mi) a[mi] = ks_frag_swz(As, (wm * MR + mi) * 32, ks, lane);
+            for (int kk = 0; kk < KG; ++kk) {
 #pragma unroll
-            for (int ni = 0; ni < NR; ++ni) b[ni] = ks_frag_swz(Bs, (wn * NR + ni) * 32, ks, lane);
+                for (int mi = 0; mi < MR; ++mi) a[kk][mi] = ks_frag_swz(As, (wm * MR + mi) * 32, kg + kk, lane);
 #pragma unroll
-            for (int mi = 0; mi < MR; ++mi)
+                for (int ni = 0; ni < NR; ++ni) b[kk][ni] = ks_frag_swz(Bs, (wn * NR + ni) * 32, kg + kk, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ni = 0; ni < NR; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NR; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][mi], b[kk][ni], acc[mi][ni], 0, 0, 0);
         }
     }
     __syncthreads();
@@ -472,12 +502,15 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         cfg = (EPI == EPI_DX && (g.N % 256) == 0 && t256 >= 192) ? 3 : t128 >= 384 ? 1 : 0;
     }
     if (cfg >= 2 && (g.N % 128) != 0) cfg = 0;
-    switch (cfg) {
-        case 1: return launch_kc<EPI, 128, 128, 2, 2, 2, VAR>(g, s);
-        case 2: return launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
-        case 3: return (g.N % 256) == 0 ? launch_kc<EPI, 256, 256, 2, 4, 2, VAR>(g, s) : launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
-        default: return launch_kc<EPI, 64, 128, 2, 2, 3, VAR>(g, s);
+    // DX epilogues that may stage a tile of e.h in LDS (softplus derivative, xhat sums) only exist for the small tiles
+    constexpr bool H_TILE = EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU;
+    if (H_TILE && cfg >= 2) cfg = 1;
+    if constexpr (!H_TILE) {
+        if (cfg == 2) return launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
+        if (cfg == 3) return (g.N % 256) == 0 ? launch_kc<EPI, 256, 256, 2, 4, 2, VAR>(g, s) : launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
     }
+    if (cfg == 1) return launch_kc<EPI, 128, 128, 2, 2, 2, VAR>(g, s);
+    return launch_kc<EPI, 64, 128, 2, 2, 3, VAR>(g, s);
 }
 
 static int launch_kc_any(int epi, const GemmArgs& g, hipStream_t s) {
