@@ -431,8 +431,7 @@ int dense_dx(mrgan_handle* h, const Dense& L, const void* dy, int rows, int nb, 
 
 // dW slabs = X^T dY.  The nseg segments ([nseg][S] rows, `rows` valid in each) form ONE virtual reduction
 // range that is cut into L.splits slabs, so the Adam kernel sums at most MAX_SLABS slabs per tensor.
-int dense_dw(mrgan_handle* h, const Dense& L, const void* x, const void* dy, int rows, int nseg, hipStream_t s) {
-    GemmArgs g;
+double dw_args(mrgan_handle* h, GemmArgs& g, const Dense& L, const void* x, const void* dy, int rows, int nseg) {
     memset(&g, 0, sizeof g);
     const int vrows = (nseg - 1) * h->S + rows;
     g.M = L.Kp; g.N = L.Np; g.K = vrows; g.nbatch = 1; g.splits = L.splits; g.tiles_m = ceil_div(L.Kp, 128);
@@ -442,7 +441,30 @@ int dense_dw(mrgan_handle* h, const Dense& L, const void* x, const void* dy, int
     g.B = dy; g.b_sk = L.Np; g.b_sj = 1;
     g.e = base_epi(h);
     g.e.ldo = L.Np; g.e.slab = L.slabs; g.e.slab_stride = (long)L.Kp * L.Np;
-    return run_gemm(h, EPI_SLAB, g, 2.0 * rows * nseg * L.K * L.N, s);
+    return 2.0 * rows * nseg * L.K * L.N;
+}
+
+struct DwJob { const Dense* L; const void* x; const void* dy; };
+
+// the weight-gradient products of one sub-step: one grouped launch when the bf16 fast path takes them all,
+// one launch per product otherwise
+int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, hipStream_t s) {
+    GemmArgs gs[KS_GROUP_MAX];
+    double fl[KS_GROUP_MAX], total = 0.0;
+    if (n > KS_GROUP_MAX) return fail(-1, "dense_dw_all: too many products");
+    for (int i = 0; i < n; ++i) { fl[i] = dw_args(h, gs[i], *jobs[i].L, jobs[i].x, jobs[i].dy, rows, nseg); total += fl[i]; }
+    if (h->bf16) {
+        const char* kname = "gemm";
+        if (h->prof && h->prof_recs.empty()) prof_mark(h, "(start)", 0, s);
+        const int r = launch_gemm_bf16_dw_group(gs, n, s, &kname);
+        if (r < 0) return fail(r, "grouped weight-gradient launch failed");
+        if (r == 0) {
+            if (h->prof) { prof_mark(h, kname, total, s); hipEventRecord(h->prof_recs.back().ev, s); }
+            return 0;
+        }
+    }
+    for (int i = 0; i < n; ++i) CHK(run_gemm(h, EPI_SLAB, gs[i], fl[i], s));
+    return 0;
 }
 
 void* rowptr(mrgan_handle* h, void* base, long row, int ld) { return (char*)base + (size_t)row * ld * h->es; }
@@ -556,7 +578,11 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         for (int l = 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 3, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_SUM, h->cs_db[l - 1], nullptr, s));
-        for (int l = 0; l < 5; ++l) CHK(dense_dw(h, h->d[l], h->xin[l], h->dpre[l], B, 3, s));
+        {
+            DwJob jobs[5];
+            for (int l = 0; l < 5; ++l) jobs[l] = DwJob{&h->d[l], h->xin[l], h->dpre[l]};
+            CHK(dense_dw_all(h, jobs, 5, B, 3, s));
+        }
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_D, ADAM_REDUCE_ONLY, true, s));
     } else if (phase == MRGAN_D_ADAM) {
         CHK(run_adam(h, MRGAN_NET_D, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, true, s));
@@ -616,9 +642,10 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         b.ldcs = N1p; b.count = h->stat_count; b.gamma = h->gt[2].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
         b.db_part = h->db1g_part;
         PROF("bn_bwd_kernel", launch_bn_bwd(h->bf16, b, s));
-        CHK(dense_dw(h, h->g[2], h->h2, h->dxfake, B, 1, s));
-        CHK(dense_dw(h, h->g[1], h->hbn, h->dpre2g, B, 1, s));
-        CHK(dense_dw(h, h->g[0], h->zbuf, h->dpre1g, B, 1, s));
+        {
+            const DwJob jobs[3] = {{&h->g[2], h->h2, h->dxfake}, {&h->g[1], h->hbn, h->dpre2g}, {&h->g[0], h->zbuf, h->dpre1g}};
+            CHK(dense_dw_all(h, jobs, 3, B, 1, s));
+        }
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_G, ADAM_REDUCE_ONLY, false, s));
     } else if (phase == MRGAN_G_ADAM) {
         CHK(run_adam(h, MRGAN_NET_G, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, false, s));
@@ -985,8 +1012,9 @@ int mrgan_debug_ablate(int bits) { g_ablate = bits; return 0; }
 int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, int reps, float* avg_us) {
     if ((n % 64) || (k % 64) || !avg_us) return fail(-1, "debug_gemm_time: bad argument");
     const size_t rows = (size_t)m * nbatch;
-    const int a_cols = op == 1 ? n : k, o_cols = op == 1 ? k : n;
-    if (op < 0 || op > 4) return fail(-1, "debug_gemm_time: bad op");
+    const bool is_dx = op == 1 || op >= 5;
+    const int a_cols = is_dx ? n : k, o_cols = is_dx ? k : n;
+    if (op < 0 || op > 8) return fail(-1, "debug_gemm_time: bad op");
     __bf16 *ta = nullptr, *tb = nullptr, *to = nullptr;
     uint16_t* mask = nullptr; float* slabs = nullptr; float* bias = nullptr; DevState* st = nullptr;
     HIPCHK(hipMalloc((void**)&ta, rows * std::max(a_cols, n) * 2));
@@ -1011,10 +1039,17 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
         g.e.act = ACT_RELU; g.e.n_valid = n; g.e.bias = bias; g.e.ldo = n; g.e.out_bs = (long)m * n;
         g.e.sigma = op == 0 ? 0.5f : 0.f; g.e.site = 1;
         if (op != 4) { g.e.mask = mask; g.e.ldm = n; g.e.mask_bs = (long)(m / 32 + 1) * n * 2; }
-    } else if (op == 1) {
+    } else if (is_dx) {
+        // 1: relu mask ; 5: softplus' with e.h + column sums ; 6: linear + xhat sums ; 7: linear + column sums ; 8: linear
         epi = EPI_DX; g.M = m; g.N = k; g.K = n; g.kchunk = n; g.a_bs = (long)m * n; g.a_si = n; g.a_sk = 1; g.b_sk = 1; g.b_sj = n;
-        g.e.act = ACT_RELU; g.e.n_valid = k; g.e.ldo = k; g.e.out_bs = (long)m * k;
-        g.e.mask = mask; g.e.ldm = k; g.e.mask_bs = (long)(m / 32 + 1) * k * 2;
+        g.e.act = op == 1 ? ACT_RELU : op == 5 ? ACT_SOFTPLUS : ACT_LINEAR; g.e.n_valid = k; g.e.ldo = k; g.e.out_bs = (long)m * k;
+        if (op == 1) { g.e.mask = mask; g.e.ldm = k; g.e.mask_bs = (long)(m / 32 + 1) * k * 2; }
+        if (op == 5 || op == 6) { g.e.h = ta; g.e.ldh = k; g.e.h_bs = (long)m * k; }
+        if (op >= 5 && op <= 7) {
+            HIPCHK(hipMalloc((void**)&slabs, (size_t)2 * (rows / 64 + 1) * k * 4));
+            g.e.cs_mode = op == 6 ? CS_SUM_XHAT : CS_SUM; g.e.cs1 = slabs; g.e.cs2 = slabs + (size_t)(rows / 64 + 1) * k; g.e.ldcs = k;
+            g.e.bn_mu = bias; g.e.bn_rstd = bias;
+        }
     } else {
         epi = EPI_SLAB; g.M = k; g.N = n; g.K = m * nbatch; g.nbatch = 1; g.splits = std::max(1, splits);
         g.kchunk = (int)round_up(ceil_div(g.K, g.splits), 64);

@@ -309,9 +309,18 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
     }
 }
 
+// up to KS_GROUP_MAX weight-gradient products launched as one grid (gemm_bf16.hip)
+constexpr int KS_GROUP_MAX = 6;
+struct KsGroup {
+    int n;
+    int blk_end[KS_GROUP_MAX];       // exclusive prefix sums of the problems' block counts
+    GemmArgs g[KS_GROUP_MAX];
+};
+
 // host-side launchers (gemm_f32.hip / gemm_bf16.hip)
 // kname (optional) receives the name of the kernel instantiation that was launched, spelled as rocprofv3 prints it
 int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
 int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
+int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname = nullptr);   // 1 = not applicable
 
 }  // namespace mrgan

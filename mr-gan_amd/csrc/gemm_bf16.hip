@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cstring>
 #include <string>
 
 #include "gemm.h"
@@ -73,13 +74,16 @@ __device__ __forceinline__ void wait_groups(int n) {
 // LDS-DMA issue is the scarce resource of this loop (~60-100 issue cycles per 1 KiB wave-instruction), so the
 // achievable MFMA share grows with the tile's arithmetic intensity BM*BNT/(BM+BNT): 64x128 -> 43, 128x128 -> 64,
 // 256x128 -> 85, 256x256 -> 128 flop per staged byte.
-template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR>
+// PIPE: the fragments of k-tile kt+1 are read from LDS into a second register set while the MFMAs of k-tile kt run
+// (needs k-tile kt+1 landed one iteration early, so NS >= 4 to keep two k-tiles of LDS-DMA in flight).  Meant for
+// launches with <= 1 block per CU, where no second block hides the barrier -> ds_read -> MFMA latency chain.
+template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR, bool PIPE = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int MR = BM / WM / 32, NR = BNT / WN / 32;   // 32x32 accumulators per wave
     constexpr int A_BYTES = BM * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BNT / 8 / NW;   // wave-instructions per wave per k-tile (8 rows each)
-    static_assert(NS >= 2 && NS <= 4, "ring depth");
+    static_assert(NS >= 2 && NS <= 4 && (!PIPE || NS >= 3), "ring depth");
     static_assert(MR >= 1 && NR >= 1 && A_INSTR >= 1 && B_INSTR >= 1 && BM % (8 * NW) == 0 && BNT % (8 * NW) == 0, "tile/wave layout");
     extern __shared__ __attribute__((aligned(16))) char lds[];        // max(NS * STAGE, BM * BNT * 2 + scratch) bytes
 
@@ -137,6 +141,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
         for (int p = 0; p < NS - 1; ++p)
             if (p < nk) issue(p * BK, p);
 
+        // DX epilogues that read e.h element-wise (softplus derivative, xhat sums: one column per lane, rows strided)
+        // get the block's tile of h copied into LDS behind the ring with 16-byte LDS-DMA loads; it lands under the main
+        // loop (the loads are older than every k-tile group issued inside the loop, so the counted waits cover them)
+        const __bf16* htile = nullptr;
+        if constexpr (EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU) {
+            if (dx_needs_h<VAR>(g.e)) {
+                constexpr int OUTB = BM * BNT * 2 + 4 * WM * BNT * 4, RING = NS * STAGE;
+                char* hdst = lds + (RING > OUTB ? RING : OUTB);
+                const __bf16* hb = (const __bf16*)g.e.h + (long)batch * g.e.h_bs;
+                const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, (int)((long)g.M * g.e.ldh * 2), 0x00020000);
+                constexpr int RPI = 1024 / (BNT * 2);              // tile rows per wave-instruction
+                constexpr int LPR = 64 / RPI;                      // lanes per row
+                constexpr int HI = BM / RPI / NW;                  // wave-instructions per wave
+#pragma unroll
+                for (int i = 0; i < HI; ++i) {
+                    const int R = (wave * HI + i) * RPI + lane / LPR;
+                    const int voff = (int)(((long)(row_blk + R) * g.e.ldh + col_blk) * 2) + (lane % LPR) * 16;
+                    glds16(rsH, hdst + (wave * HI + i) * 1024, voff, 0);
+                }
+                htile = (const __bf16*)hdst;
+            }
+        }
+
         f32x16 acc[MR][NR];
 #pragma unroll
         for (int i = 0; i < MR; ++i)
@@ -150,70 +177,100 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
         EpiPrefetch<MR, NR> pf;
         epilogue_prefetch<__bf16, EPI, MR, NR, VAR>(pf, g, batch, row_blk, col_blk, wm, wn, lane);
 
-        int buf = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            // vmcnt counts in issue order (stores of the previous tile and the prefetch loads are older than or as old
-            // as the group being waited for, so waiting for the group also retires them)
-            if (kt == 0) STAMP(0);                                        // tile setup + issue
-            wait_groups<A_INSTR + B_INSTR>(min(NS - 2, nk - 1 - kt));   // this wave's loads of k-tile kt have landed
-            __builtin_amdgcn_s_barrier();                                 // ... everyone's; everyone finished k-tile kt-1
-            asm volatile("" ::: "memory");
-            if (kt == 0) STAMP(1);                                        // first k-tile landed (pipeline fill)
-            if (kt + NS - 1 < nk) {                                       // refill the stage read during k-tile kt-1
-                int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
-                issue((kt + NS - 1) * BK, nb);
-            }
-            const char* As = lds + buf * STAGE;
-            const char* Bs = As + A_BYTES;
-            buf = (buf + 1 == NS) ? 0 : buf + 1;
-            // fragments of KG k-steps are fetched as one batch ahead of their MFMAs: the LDS latency is paid once per
-            // batch (counted lgkmcnt waits) instead of once per MFMA
-            constexpr int KG = (MR + NR <= 4) ? 4 : 2;
-#pragma unroll
-            for (int kg = 0; kg < BK / 16; kg += KG) {
-                bf16x8 a[KG][MR], b[KG][NR];
-#pragma unroll
-                for (int kk = 0; kk < KG; ++kk) {
-#pragma unroll
-                    for (int mi = 0; mi < MR; ++mi) a[kk][mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, (kg + kk) * 2 + lh));
-#pragma unroll
-                    for (int ni = 0; ni < NR; ++ni) b[kk][ni] = *(const bf16x8*)(Bs + kc_off((wn * NR + ni) * 32 + lr, (kg + kk) * 2 + lh));
+        if constexpr (!PIPE) {
+            int buf = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                // vmcnt counts in issue order (stores of the previous tile and the prefetch loads are older than or as old
+                // as the group being waited for, so waiting for the group also retires them)
+                if (kt == 0) STAMP(0);                                        // tile setup + issue
+                wait_groups<A_INSTR + B_INSTR>(min(NS - 2, nk - 1 - kt));   // this wave's loads of k-tile kt have landed
+                __builtin_amdgcn_s_barrier();                                 // ... everyone's; everyone finished k-tile kt-1
+                asm volatile("" ::: "memory");
+                if (kt == 0) STAMP(1);                                        // first k-tile landed (pipeline fill)
+                if (kt + NS - 1 < nk) {                                       // refill the stage read during k-tile kt-1
+                    int nb = buf + NS - 1; if (nb >= NS) nb -= NS;
+                    issue((kt + NS - 1) * BK, nb);
                 }
-                __builtin_amdgcn_sched_barrier(0);       // keep the scheduler from re-serialising read -> wait -> MFMA
+                const char* As = lds + buf * STAGE;
+                const char* Bs = As + A_BYTES;
+                buf = (buf + 1 == NS) ? 0 : buf + 1;
+                // fragments of KG k-steps are fetched as one batch ahead of their MFMAs: the LDS latency is paid once per
+                // batch (counted lgkmcnt waits) instead of once per MFMA
+                constexpr int KG = (MR + NR <= 4) ? 4 : 2;
+    #pragma unroll
+                for (int kg = 0; kg < BK / 16; kg += KG) {
+                    bf16x8 a[KG][MR], b[KG][NR];
+    #pragma unroll
+                    for (int kk = 0; kk < KG; ++kk) {
+    #pragma unroll
+                        for (int mi = 0; mi < MR; ++mi) a[kk][mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, (kg + kk) * 2 + lh));
+    #pragma unroll
+                        for (int ni = 0; ni < NR; ++ni) b[kk][ni] = *(const bf16x8*)(Bs + kc_off((wn * NR + ni) * 32 + lr, (kg + kk) * 2 + lh));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // keep the scheduler from re-serialising read -> wait -> MFMA
+    #pragma unroll
+                    for (int kk = 0; kk < KG; ++kk)
+    #pragma unroll
+                        for (int mi = 0; mi < MR; ++mi)
+    #pragma unroll
+                            for (int ni = 0; ni < NR; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][mi], b[kk][ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        } else {
+            constexpr int KS = BK / 16;
+            auto read_frags = [&](bf16x8 (&fa)[KS][MR], bf16x8 (&fb)[KS][NR], int stage) {
+                const char* As = lds + stage * STAGE;
+                const char* Bs = As + A_BYTES;
 #pragma unroll
-                for (int kk = 0; kk < KG; ++kk)
+                for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+                    for (int mi = 0; mi < MR; ++mi) fa[kk][mi] = *(const bf16x8*)(As + kc_off((wm * MR + mi) * 32 + lr, kk * 2 + lh));
+#pragma unroll
+                    for (int ni = 0; ni < NR; ++ni) fb[kk][ni] = *(const bf16x8*)(Bs + kc_off((wn * NR + ni) * 32 + lr, kk * 2 + lh));
+                }
+            };
+            bf16x8 fa0[KS][MR], fb0[KS][NR], fa1[KS][MR], fb1[KS][NR];
+            int stg = 0;                                                    // stage of k-tile kt
+            // one pipeline step: on entry the reads of k-tile kt's fragments into (ca, cb) have been issued
+            auto step = [&](bf16x8 (&ca)[KS][MR], bf16x8 (&cb)[KS][NR], bf16x8 (&na)[KS][MR], bf16x8 (&nb)[KS][NR], int kt) {
+                int s1 = stg + 1; if (s1 >= NS) s1 -= NS;                   // stage of k-tile kt+1
+                if (kt + 1 < nk) wait_groups<A_INSTR + B_INSTR>(min(NS - 3, nk - 2 - kt));   // k-tile kt+1 has landed (this wave)
+                __builtin_amdgcn_s_barrier();     // ... everyone's; and every wave has its k-tile kt-1 fragments in registers
+                asm volatile("" ::: "memory");
+                if (kt + NS - 1 < nk) {                                     // refill the stage of k-tile kt-1
+                    int nb = stg - 1; if (nb < 0) nb += NS;
+                    issue((kt + NS - 1) * BK, nb);
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0), as a builtin so that the compiler's own wait insertion
+                                                       // knows (ca, cb) are complete (issued a whole k-tile ago)
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nk) read_frags(na, nb, s1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
                     for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NR; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk][mi], b[kk][ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[kk][mi], cb[kk][ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                stg = s1;
+            };
+            if (nk > 0) {
+                wait_groups<A_INSTR + B_INSTR>(min(NS - 2, nk - 1));
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                read_frags(fa0, fb0, 0);
             }
+            int kt = 0;
+            for (; kt + 1 < nk; kt += 2) { step(fa0, fb0, fa1, fb1, kt); step(fa1, fb1, fa0, fb0, kt + 1); }
+            if (kt < nk) step(fa0, fb0, fa1, fb1, kt);
         }
         STAMP(2);               // main loop
         __syncthreads();
         STAMP(3);               // barrier after the main loop
         // the BM x BNT bf16 output tile is assembled at the start of the (now dead) ring, column-sum scratch behind it
-        const __bf16* htile = nullptr;
-        if constexpr (EPI == EPI_DX) {
-            // DX epilogues that read e.h element-wise (one column per lane, rows strided) get the block's tile of h
-            // copied into LDS with 16-byte LDS-DMA loads first: one round trip instead of one per element.
-            if (dx_needs_h<VAR>(g.e)) {
-                char* hdst = lds + BM * BNT * 2 + 4 * WM * BNT * 4;
-                const __bf16* hb = (const __bf16*)g.e.h + (long)batch * g.e.h_bs;
-                const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, (int)((long)g.M * g.e.ldh * 2), 0x00020000);
-                constexpr int RPI = 1024 / (BNT * 2);              // tile rows per wave-instruction
-                constexpr int LPR = 64 / RPI;                      // lanes per row
-#pragma unroll
-                for (int i = 0; i < BM / RPI / NW; ++i) {
-                    const int R = (wave * (BM / RPI / NW) + i) * RPI + lane / LPR;
-                    const int voff = (int)(((long)(row_blk + R) * g.e.ldh + col_blk) * 2) + (lane % LPR) * 16;
-                    glds16(rsH, hdst + (wave * (BM / RPI / NW) + i) * 1024, voff, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                htile = (const __bf16*)hdst;
-            }
-        }
         epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
                                                      (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf, htile);
         STAMP(4);               // epilogue (math, staging, copy-out issue, column sums)
@@ -228,19 +285,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
 
 thread_local const char* g_last_kernel = "";
 
-template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR>
+template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR, bool PIPE = false>
 int launch_kc(const GemmArgs& g, hipStream_t s) {
     static const std::string name = "gemm_bf16_kc_kernel<" + std::to_string(EPI) + ", " + std::to_string(BM) + ", " +
                                     std::to_string(BNT) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
-                                    std::to_string(NS) + ", " + std::to_string(VAR) + ">";
+                                    std::to_string(NS) + ", " + std::to_string(VAR) + (PIPE ? ", true>" : ">");
     g_last_kernel = name.c_str();
     constexpr int STAGE = BM * 128 + BNT * 128;
     // staged output tile + column-sum scratch (+ the tile of e.h for the DX epilogues that read it)
-    constexpr int OUT = BM * BNT * 2 + 4 * WM * BNT * 4 + ((EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU) ? BM * BNT * 2 : 0);
-    static_assert(OUT <= 160 * 1024, "LDS budget");
-    constexpr int LDS = NS * STAGE > OUT ? NS * STAGE : OUT;
+    constexpr int OUT = BM * BNT * 2 + 4 * WM * BNT * 4;
+    constexpr int LDS = (NS * STAGE > OUT ? NS * STAGE : OUT) + ((EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU) ? BM * BNT * 2 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
-    auto kern = gemm_bf16_kc_kernel<EPI, BM, BNT, WM, WN, NS, VAR>;
+    auto kern = gemm_bf16_kc_kernel<EPI, BM, BNT, WM, WN, NS, VAR, PIPE>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
         attr_done = true;
@@ -271,7 +328,7 @@ __device__ __forceinline__ bf16x8 ks_frag_swz(const char* tile, int fb, int ks, 
 }
 
 template <int NS, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_fast_kernel(const GemmArgs g) {
+__device__ __forceinline__ void ks_fast_body(const GemmArgs& g, const int bid) {
     constexpr int NW = WM * WN;
     constexpr int MR = 128 / WM / 32, NR = 128 / WN / 32;
     constexpr int T_BYTES = 64 * 256, STAGE = 2 * T_BYTES;
@@ -283,7 +340,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_fast_kernel(const G
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = (g.N + 127) / 128, ntm = (g.M + 127) / 128;
-    const int tidx = xcd_tile(blockIdx.x, ntn * ntm * g.splits);
+    const int tidx = xcd_tile(bid, ntn * ntm * g.splits);
     const int split = tidx / (ntn * ntm), rem = tidx - split * (ntn * ntm);
     const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
     const int row_blk = tile_m * 128, col_blk = tile_n * 128;
@@ -358,6 +415,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_fast_kernel(const G
     }
     __syncthreads();
     epilogue<__bf16, EPI_SLAB, MR, NR, WM>(acc, g, 0, split, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BN);
+}
+
+template <int NS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_fast_kernel(const GemmArgs g) {
+    ks_fast_body<NS, WM, WN>(g, blockIdx.x);
+}
+
+// All weight-gradient products of one sub-step in ONE launch: they have no consumer before the Adam kernel, each is
+// small (32 .. 256 blocks, 5-7 us of launch + drain per launch for 3-12 us of work), and together they fill the chip.
+// Block b works on problem i with blk_end[i-1] <= b < blk_end[i]; every count is a multiple of 8, so the block's XCD
+// (b % 8) is also its XCD inside the problem and the XCD-aware tile order of ks_fast_body stays valid.
+template <int NS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_group_kernel(const KsGroup grp) {
+    int i = 0, b0 = 0;
+#pragma unroll
+    for (int j = 0; j < KS_GROUP_MAX - 1; ++j)
+        if (j + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[j]) { i = j + 1; b0 = grp.blk_end[j]; }
+    ks_fast_body<NS, WM, WN>(grp.g[i], (int)blockIdx.x - b0);
 }
 
 template <int NS, int WM, int WN>
@@ -510,6 +585,11 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         if (cfg == 3) return (g.N % 256) == 0 ? launch_kc<EPI, 256, 256, 2, 4, 2, VAR>(g, s) : launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
     }
     if (cfg == 1) return launch_kc<EPI, 128, 128, 2, 2, 2, VAR>(g, s);
+    // cfg 4 / MRGAN_KC_PIPE=1 (launches with at most one 64x128 tile per CU): pipelined fragments, 4-stage ring.
+    // Measured no faster than cfg 0 on MI355X -- these launches are bound by the L2 -> LDS fill, not by the LDS -> MFMA chain.
+    static const int pipe = env_int("MRGAN_KC_PIPE", 0);
+    const int t64 = ceil_div(g.M, 64) * ceil_div(g.N, 128) * g.nbatch;
+    if (cfg == 4 || (forced < 0 && pipe && t64 <= 256)) return launch_kc<EPI, 64, 128, 2, 2, 4, VAR, true>(g, s);
     return launch_kc<EPI, 64, 128, 2, 2, 3, VAR>(g, s);
 }
 
@@ -528,6 +608,41 @@ static int launch_kc_any(int epi, const GemmArgs& g, hipStream_t s) {
     if (e.act == ACT_RELU) return launch_kc_tile<EPI_DX, ACT_RELU>(g, s);
     if (e.act == ACT_SOFTPLUS) return launch_kc_tile<EPI_DX, ACT_SOFTPLUS>(g, s);
     return launch_kc_tile<EPI_DX, ACT_LINEAR>(g, s);
+}
+
+static bool ks_dense_k(const GemmArgs& g) {
+    return g.a_si == 1 && g.b_sj == 1 && g.nbatch == 1 && (g.K % BK) == 0 && (g.kchunk % BK) == 0 &&
+           (g.seg_rows >= g.seg_stride || g.K <= g.seg_rows) &&
+           (long)g.K * g.a_sk * 2 < (1L << 31) && (long)g.K * g.b_sk * 2 < (1L << 31);
+}
+
+// n weight-gradient products as one launch; returns 1 (nothing launched) when a problem does not fit the grouped kernel
+int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname) {
+    if (n < 1 || n > KS_GROUP_MAX) return 1;
+    static const int enabled = env_int("MRGAN_KS_GROUP", 1);
+    if (!enabled) return 1;
+    KsGroup grp;
+    memset(&grp, 0, sizeof grp);
+    grp.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!ks_dense_k(gs[i])) return 1;
+        const int blocks = ceil_div(gs[i].N, 128) * ceil_div(gs[i].M, 128) * gs[i].splits;
+        if (blocks % 8) return 1;
+        total += blocks;
+        grp.blk_end[i] = total;
+        grp.g[i] = gs[i];
+    }
+    constexpr int NS = 3, WM = 2, WN = 4, STAGE = 2 * 64 * 256;
+    static bool attr_done = false;
+    auto kern = gemm_bf16_ks_group_kernel<NS, WM, WN>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE) != hipSuccess) return -2;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), NS * STAGE, s, grp);
+    if (kname) *kname = "gemm_bf16_ks_group_kernel<3, 2, 4>";
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kname) {

@@ -16,6 +16,11 @@ SHAPES = [  # (name, op, m, n, k, nbatch, splits)
     ("fwd G2 Bx512->512", 0, B, 512, 512, 1, 1),
     ("dx  D2 3B:512->1024", 1, B, 512, 1024, 3, 1),
     ("dx  D3 3B:256->512", 1, B, 256, 512, 3, 1),
+    ("dx  G3 softplus'+h+cs", 5, B, 512, 512, 1, 1),
+    ("dx  G2 linear+xhat", 6, B, 512, 512, 1, 1),
+    ("dx  G2 linear+colsum", 7, B, 512, 512, 1, 1),
+    ("dx  G2 linear", 8, B, 512, 512, 1, 1),
+    ("dx  D1 B:1024->512 +cs", 7, B, 1024, 512, 1, 1),
     ("dw  D1 512x1024 /3B", 2, B, 1024, 512, 3, 8),
     ("dw  D3 512x256 /3B", 2, B, 256, 512, 3, 16),
     ("dw  D4 256x256 /3B", 2, B, 256, 256, 3, 16),
