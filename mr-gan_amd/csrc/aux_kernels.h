@@ -15,6 +15,7 @@ struct StageSeg {
     float sigma; uint32_t site, seg;
     int gen;                                        // 1: out = N(0,1) only (z drawn on device), src ignored
     int stream;                                     // 1: o = batch * rows from the device batch counter
+    uint32_t iter_off;                              // noise key uses DevState::iter + iter_off (z of a later sub-step)
 };
 struct StageArgs {
     StageSeg s[4]; int nseg;
@@ -31,6 +32,8 @@ struct BnApplyArgs {
     float count, eps;                                          // global batch size
     const float* gamma; const float* beta;
     float* mu; float* rstd;                                    // saved for the backward pass
+    int nseg; long seg_rows;                                   // nseg independent batches, seg_rows rows apart in h / out; their
+                                                               // partial sums follow each other (npart rows each), mu / rstd ld apart
 };
 int launch_bn_apply(int bf16, const BnApplyArgs& a, hipStream_t s);
 

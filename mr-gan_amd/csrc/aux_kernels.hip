@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) nz[c][j] = 0.f;
     if (sg.gen || sg.sigma > 0.f) {
-        const uint32_t nkey = noise_key(a.seed, sg.site * 256u + sg.seg, st.iter);
+        const uint32_t nkey = noise_key(a.seed, sg.site * 256u + sg.seg, st.iter + sg.iter_off);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c0 + c < sg.cols) normal4(nkey, (a.row0 + (uint32_t)r4) >> 2, (uint32_t)(c0 + c), nz[c]);
@@ -135,9 +135,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
     __shared__ float sc[CB], sh[CB];
     __shared__ float scr[16][CB], f1[CB], f2[CB];
-    const int t = threadIdx.x, col0 = blockIdx.x * CB;
-    fold_partials(a.cs1, a.npart, a.ldcs, col0, a.ld, scr, f1);
-    fold_partials(a.cs2, a.npart, a.ldcs, col0, a.ld, scr, f2);
+    const int t = threadIdx.x, col0 = blockIdx.x * CB, seg = blockIdx.z;
+    fold_partials(a.cs1 + (long)seg * a.npart * a.ldcs, a.npart, a.ldcs, col0, a.ld, scr, f1);
+    fold_partials(a.cs2 + (long)seg * a.npart * a.ldcs, a.npart, a.ldcs, col0, a.ld, scr, f2);
     if (t < CB) {
         const int col = col0 + t;
         float scale = 0.f, shift = 0.f;
@@ -146,15 +146,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
             const float var = fmaxf(f2[t] / a.count - mean * mean, 0.f);
             const float rstd = 1.0f / sqrtf(var + a.eps);
             if (col < a.cols) { scale = a.gamma[col] * rstd; shift = a.beta[col] - mean * scale; }
-            if (blockIdx.y == 0) { a.mu[col] = mean; a.rstd[col] = rstd; }
+            if (blockIdx.y == 0) { a.mu[(long)seg * a.ld + col] = mean; a.rstd[(long)seg * a.ld + col] = rstd; }
         }
         sc[t] = scale; sh[t] = shift;
     }
     __syncthreads();
     const int cg = t & 7, rl = t >> 3, c0 = col0 + cg * 8;
     if (c0 >= a.ld) return;
-    const T* h = (const T*)a.h;
-    T* out = (T*)a.out;
+    const T* h = (const T*)a.h + (long)seg * a.seg_rows * a.ld;
+    T* out = (T*)a.out + (long)seg * a.seg_rows * a.ld;
     const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
     for (int r = blockIdx.y * RB + rl; r < r1; r += 32) {
         float v[8];
@@ -593,7 +593,7 @@ int launch_stage(int bf16, const StageArgs& a, hipStream_t s) {
 }
 
 int launch_bn_apply(int bf16, const BnApplyArgs& a, hipStream_t s) {
-    dim3 grid(ceil_div(a.ld, CB), ceil_div(a.rows, RB));
+    dim3 grid(ceil_div(a.ld, CB), ceil_div(a.rows, RB), std::max(1, a.nseg));
     LAUNCH_T(bn_apply_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }

@@ -96,12 +96,16 @@ struct mrgan_handle {
     float *r_bn_stats, *r_fm, *r_bn_bwd;
 
     // activations (T = float | __bf16)
-    void *zbuf, *h1, *hbn, *h2;
+    void *zbuf, *h1, *hbn, *h2;          // the generator activations the current sub-step works on (views into *_all)
+    void *zbuf_all, *h1_all, *hbn_all, *h2_all;   // [2][S] rows: segment 1 = the G sub-step's batch when a pair runs its two
+                                                  // generator forwards as one (pair_gen)
+    int pair_gen, gen_ready;             // train_pair: D_GEN also ran the G sub-step's generator forward
+    int xbase;                           // first xin[0] slot of the current G sub-step (0, or 3 after a paired forward)
     void* xin[5]; void* feat; uint16_t* mask[5]; int ldm[5];
     void* dpre[5];
     void *dxfake, *dpre2g, *dhbn, *dpre1g;
     float* logits;
-    float *bn_mu, *bn_rstd;
+    float *bn_mu, *bn_rstd, *bn_mu_all, *bn_rstd_all;
     // partial sums
     float *cs_bn1, *cs_bn2, *cs_db[4], *cs_f, *cs_db3g, *cs_db2g, *cs_dbeta, *cs_dgamma, *db1g_part;
     float *head_part, *head_red, *loss_part; int head_stride, head_groups;
@@ -248,16 +252,17 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->r_bn_stats = a.take<float>(2 * N1p);
     h->r_fm = a.take<float>(2 * h->Fp);
     h->r_bn_bwd = a.take<float>(2 * N1p);
-    h->bn_mu = a.take<float>(N1p);
-    h->bn_rstd = a.take<float>(N1p);
+    h->bn_mu_all = a.take<float>(2 * N1p);
+    h->bn_rstd_all = a.take<float>(2 * N1p);
 
     // ---- activations ---------------------------------------------------------------------------
     const size_t es = h->es;
     auto act = [&](size_t rows, size_t cols) { return (void*)a.take<char>(rows * cols * es); };
-    h->zbuf = act(S, h->nzp);
-    h->h1 = act(S, N1p); h->hbn = act(S, N1p); h->h2 = act(S, h->g[1].Np);
+    h->zbuf_all = act(2 * (size_t)S, h->nzp);
+    h->h1_all = act(2 * (size_t)S, N1p); h->hbn_all = act(2 * (size_t)S, N1p); h->h2_all = act(2 * (size_t)S, h->g[1].Np);
     for (int l = 0; l < 5; ++l) {
-        h->xin[l] = act(3 * (size_t)S, h->d[l].Kp);
+        // xin[0]: slots 0..2 = the D sub-step's segments, 3..4 = the G sub-step's (fake, real) after a paired forward
+        h->xin[l] = act((l == 0 ? 5 : 3) * (size_t)S, h->d[l].Kp);
         h->ldm[l] = h->d[l].Np;                                   // lane-native relu mask: 2 x u16 per (32 rows, column)
         h->mask[l] = a.take<uint16_t>(3 * (size_t)(S / 32) * h->ldm[l] * 2);
         h->dpre[l] = act(3 * (size_t)S, h->d[l].Np);
@@ -267,7 +272,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->logits = a.take<float>(3 * (size_t)S * KMAX);
 
     // ---- partial sums ----------------------------------------------------------------------------
-    h->cs_bn1 = a.take<float>((size_t)tm * N1p); h->cs_bn2 = a.take<float>((size_t)tm * N1p);
+    h->cs_bn1 = a.take<float>(2 * (size_t)tm * N1p); h->cs_bn2 = a.take<float>(2 * (size_t)tm * N1p);
     for (int l = 0; l < 4; ++l) h->cs_db[l] = a.take<float>(3 * (size_t)tm * h->d[l].Np);
     h->cs_f = a.take<float>(2 * (size_t)tm * h->Fp);
     h->cs_db3g = a.take<float>((size_t)tm * h->Dp);
@@ -387,12 +392,14 @@ Epi base_epi(mrgan_handle* h) {
     e.row0 = (uint32_t)(h->cfg.rank * h->B);
     e.st = h->state + h->cur;
     e.ablate = g_ablate;
+    e.seg_step = 1;
     return e;
 }
 
 // Y = act(X W + b): X [nb][S][Kp] -> out [nb][S][Np]
 int dense_fwd(mrgan_handle* h, const Dense& L, const void* x, int rows, int nb, void* out, int act, float sigma, uint32_t site,
-              uint32_t seg0, uint16_t* mask, int ldm, int cs_mode, float* cs1, float* cs2, bool noise_state, hipStream_t s) {
+              uint32_t seg0, uint16_t* mask, int ldm, int cs_mode, float* cs1, float* cs2, bool noise_state, hipStream_t s,
+              int seg_step = 1, uint32_t iter_step = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.M = rows; g.N = L.Np; g.K = L.Kp; g.nbatch = nb; g.splits = 1; g.kchunk = L.Kp; g.tiles_m = ceil_div(rows, 64);
@@ -404,7 +411,7 @@ int dense_fwd(mrgan_handle* h, const Dense& L, const void* x, int rows, int nb, 
     if (!noise_state) g.e.st = nullptr;
     g.e.act = act; g.e.n_valid = L.N; g.e.bias = L.b->p;
     g.e.out = out; g.e.out_bs = (long)h->S * L.Np; g.e.ldo = L.Np;
-    g.e.sigma = sigma; g.e.site = site; g.e.seg0 = seg0;
+    g.e.sigma = sigma; g.e.site = site; g.e.seg0 = seg0; g.e.seg_step = seg_step; g.e.iter_step = iter_step;
     g.e.mask = mask; g.e.mask_bs = (long)(h->S / 32) * ldm * 2; g.e.ldm = ldm;
     g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Np;
     return run_gemm(h, EPI_FWD, g, 2.0 * rows * nb * L.K * L.N, s);
@@ -485,9 +492,22 @@ int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t 
     return 0;
 }
 
-// generator forward up to the BatchNorm statistics (phase *_GEN) and from there to the fake rows
-int gen_fwd_head(mrgan_handle* h, hipStream_t s) {
-    CHK(dense_fwd(h, h->g[0], h->zbuf, h->B, 1, h->h1, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_SUM_SQ, h->cs_bn1, h->cs_bn2,
+// which of the two generator-activation segments the following kernels work on
+void set_gen_view(mrgan_handle* h, int seg) {
+    const int N1p = h->g[0].Np;
+    h->zbuf = rowptr(h, h->zbuf_all, (long)seg * h->S, h->nzp);
+    h->h1 = rowptr(h, h->h1_all, (long)seg * h->S, N1p);
+    h->hbn = rowptr(h, h->hbn_all, (long)seg * h->S, N1p);
+    h->h2 = rowptr(h, h->h2_all, (long)seg * h->S, h->g[1].Np);
+    h->bn_mu = h->bn_mu_all + (size_t)seg * N1p;
+    h->bn_rstd = h->bn_rstd_all + (size_t)seg * N1p;
+}
+
+// generator forward up to the BatchNorm statistics (phase *_GEN) and from there to the fake rows.
+// nb = 2 (pair_gen): segment 0 is this D sub-step's batch, segment 1 the following G sub-step's (its z, noise
+// iteration and noise segment id are those the G sub-step would use on its own, so the results are identical).
+int gen_fwd_head(mrgan_handle* h, int nb, hipStream_t s) {
+    CHK(dense_fwd(h, h->g[0], h->zbuf, h->B, nb, h->h1, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_SUM_SQ, h->cs_bn1, h->cs_bn2,
                   true, s));
     if (h->sync_stats) {
         const int n = h->g[0].Np;
@@ -496,42 +516,53 @@ int gen_fwd_head(mrgan_handle* h, hipStream_t s) {
     }
     return 0;
 }
-int gen_fwd_tail(mrgan_handle* h, int fake_seg_slot, uint32_t fake_seg_id, hipStream_t s) {
+int gen_fwd_tail(mrgan_handle* h, int nb, int fake_seg_slot, uint32_t fake_seg_id, hipStream_t s) {
     const int n = h->g[0].Np;
     BnApplyArgs b;
     memset(&b, 0, sizeof b);
     b.h = h->h1; b.out = h->hbn; b.ld = n; b.rows = h->B; b.cols = h->g[0].N;
+    b.nseg = nb; b.seg_rows = h->S;
     if (h->sync_stats) { b.cs1 = h->r_bn_stats; b.cs2 = h->r_bn_stats + n; b.npart = 1; }
     else { b.cs1 = h->cs_bn1; b.cs2 = h->cs_bn2; b.npart = h->tiles_m; }
     b.ldcs = n; b.count = h->stat_count; b.eps = h->cfg.bn_eps;
     b.gamma = h->gt[2].p; b.beta = h->gt[3].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
     PROF("bn_apply_kernel", launch_bn_apply(h->bf16, b, s));
-    CHK(dense_fwd(h, h->g[1], h->hbn, h->B, 1, h->h2, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_NONE, nullptr, nullptr, true, s));
-    // generator output + GaussianNoise(sigma0) = the discriminator's noisy input rows of the fake segment
+    CHK(dense_fwd(h, h->g[1], h->hbn, h->B, nb, h->h2, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_NONE, nullptr, nullptr, true, s));
+    // generator output + GaussianNoise(sigma0) = the discriminator's noisy input rows of the fake segment.
+    // Paired: segment 1 lands in the next xin[0] slot and is drawn as (segment id 0, iteration + 1), the G sub-step's fake rows.
     void* out = rowptr(h, h->xin[0], (long)fake_seg_slot * h->S, h->Dp);
-    CHK(dense_fwd(h, h->g[2], h->h2, h->B, 1, out, ACT_LINEAR, h->cfg.sigma[0], 0, fake_seg_id, nullptr, 0, CS_NONE, nullptr,
-                  nullptr, true, s));
+    CHK(dense_fwd(h, h->g[2], h->h2, h->B, nb, out, ACT_LINEAR, h->cfg.sigma[0], 0, fake_seg_id, nullptr, 0, CS_NONE, nullptr,
+                  nullptr, true, s, nb > 1 ? -(int)fake_seg_id : 1, nb > 1 ? 1u : 0u));
     return 0;
 }
 
 // discriminator dense 1..5 over nb segments (learning phase 1: noise on)
-int disc_fwd_train(mrgan_handle* h, int nb, bool fm_sums, hipStream_t s) {
+int disc_fwd_train(mrgan_handle* h, int nb, bool fm_sums, int x0_slot, hipStream_t s) {
     for (int l = 0; l < 5; ++l) {
+        const void* in = l == 0 ? rowptr(h, h->xin[0], (long)x0_slot * h->S, h->Dp) : h->xin[l];
         void* out = l < 4 ? h->xin[l + 1] : h->feat;
         const float sigma = l < 4 ? h->cfg.sigma[l + 1] : 0.f;
         const bool last = l == 4;
-        CHK(dense_fwd(h, h->d[l], h->xin[l], h->B, nb, out, ACT_RELU, sigma, (uint32_t)(l + 1), 0, h->mask[l], h->ldm[l],
+        CHK(dense_fwd(h, h->d[l], in, h->B, nb, out, ACT_RELU, sigma, (uint32_t)(l + 1), 0, h->mask[l], h->ldm[l],
                       (last && fm_sums) ? CS_SUM : CS_NONE, h->cs_f, nullptr, true, s));
     }
     return 0;
 }
 
-int stage_common(StageArgs& st, mrgan_handle* h, const float* z, int stream_mode, int advance_batch, int slot) {
-    StageSeg& zs = st.s[slot];
-    memset(&zs, 0, sizeof zs);
-    zs.src = z; zs.ld = h->cfg.noise_size; zs.rows = h->B; zs.cols = h->cfg.noise_size; zs.cols_pad = h->nzp;
-    zs.out = h->zbuf; zs.ldo = h->nzp; zs.sigma = 0.f; zs.site = SITE_Z; zs.seg = 0; zs.gen = z ? 0 : 1; zs.stream = z ? stream_mode : 0;
-    st.nseg = slot + 1;
+int stage_common(StageArgs& st, mrgan_handle* h, const float* z, int stream_mode, int advance_batch, int slot, bool paired_z = false) {
+    if (slot >= 0) {
+        StageSeg& zs = st.s[slot];
+        memset(&zs, 0, sizeof zs);
+        zs.src = z; zs.ld = h->cfg.noise_size; zs.rows = h->B; zs.cols = h->cfg.noise_size; zs.cols_pad = h->nzp;
+        zs.out = h->zbuf; zs.ldo = h->nzp; zs.sigma = 0.f; zs.site = SITE_Z; zs.seg = 0; zs.gen = z ? 0 : 1; zs.stream = z ? stream_mode : 0;
+        st.nseg = slot + 1;
+        if (paired_z) {                                 // the following G sub-step's z (drawn on device at iteration + 1)
+            StageSeg& z2 = st.s[slot + 1];
+            z2 = zs;
+            z2.out = rowptr(h, h->zbuf_all, h->S, h->nzp); z2.gen = 1; z2.src = nullptr; z2.stream = 0; z2.iter_off = 1;
+            st.nseg = slot + 2;
+        }
+    }
     st.seed = h->cfg.seed; st.row0 = (uint32_t)(h->cfg.rank * h->B);
     st.cur = h->state + h->cur; st.next = h->state + (h->cur ^ 1); st.advance_batch = advance_batch;
     st.lr = h->cfg.lr; st.b1 = h->cfg.beta1; st.b2 = h->cfg.beta2;
@@ -554,12 +585,14 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         memset(&st, 0, sizeof st);
         data_seg(st.s[0], h, a->x_lab_dev, a->idx_lab_dev, a->ld_x_lab, 0, 0, a->stream_mode);
         data_seg(st.s[1], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);
-        stage_common(st, h, a->z_dev, a->stream_mode, 0, 2);
+        set_gen_view(h, 0);
+        stage_common(st, h, a->z_dev, a->stream_mode, 0, 2, h->pair_gen != 0);
         PROF("stage_kernel", launch_stage(h->bf16, st, s));
-        CHK(gen_fwd_head(h, s));
+        CHK(gen_fwd_head(h, h->pair_gen ? 2 : 1, s));
     } else if (phase == MRGAN_D_MAIN) {
-        CHK(gen_fwd_tail(h, 2, 2, s));
-        CHK(disc_fwd_train(h, 3, false, s));
+        CHK(gen_fwd_tail(h, h->pair_gen ? 2 : 1, 2, 2, s));               // fake rows -> slot 2 (+ the G sub-step's -> slot 3)
+        h->gen_ready = h->pair_gen;
+        CHK(disc_fwd_train(h, 3, false, 0, s));
         HeadArgs hd;
         memset(&hd, 0, sizeof hd);
         hd.f = h->feat; hd.f_bs = (long)h->S * h->Fp; hd.ldf = h->Fp; hd.rows = B; hd.nseg = 3;
@@ -599,13 +632,21 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
     if (phase == MRGAN_G_GEN) {
         StageArgs st;
         memset(&st, 0, sizeof st);
-        data_seg(st.s[0], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);   // real rows -> slot 1
-        stage_common(st, h, a->z_dev, a->stream_mode, a->stream_mode ? 1 : 0, 1);
+        // after a paired forward (train_pair) the fake rows already sit in slot 3 and the generator activations in
+        // segment 1; otherwise this sub-step runs its own generator forward into slot 0 / segment 0
+        const bool ready = h->gen_ready && !a->z_dev;
+        h->gen_ready = ready ? 1 : 0;
+        h->xbase = ready ? 3 : 0;
+        set_gen_view(h, ready ? 1 : 0);
+        data_seg(st.s[0], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, h->xbase + 1, 1, a->stream_mode);   // real rows
+        st.nseg = 1;
+        stage_common(st, h, a->z_dev, a->stream_mode, a->stream_mode ? 1 : 0, ready ? -1 : 1);
         PROF("stage_kernel", launch_stage(h->bf16, st, s));
-        CHK(gen_fwd_head(h, s));
+        if (!ready) CHK(gen_fwd_head(h, 1, s));
     } else if (phase == MRGAN_G_FEAT) {
-        CHK(gen_fwd_tail(h, 0, 0, s));                                                          // fake rows -> slot 0
-        CHK(disc_fwd_train(h, 2, true, s));
+        if (!h->gen_ready) CHK(gen_fwd_tail(h, 1, 0, 0, s));                                    // fake rows -> slot 0
+        h->gen_ready = 0;
+        CHK(disc_fwd_train(h, 2, true, h->xbase, s));
         if (h->sync_stats) {
             PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f, tm, h->Fp, h->Fp, h->r_fm, s));
             PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm + h->Fp, s));
@@ -759,6 +800,7 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
     }
     h->ws_bytes = need;
     layout(h, h->ws, &need);
+    set_gen_view(h, 0);
     h->cur = 0; h->graph_ready = false; h->graph_exec = nullptr; h->prof = false;
     if (init_kernel_attributes() != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "hipFuncSetAttribute failed"); }
 #define CREATE_CHK(x)                                           \
@@ -892,11 +934,19 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     const bool want_graph = !h->prof && (h->cfg.flags & MRGAN_FLAG_GRAPH) && d->stream_mode && g->stream_mode && !h->flat_grads && !h->sync_stats;
-    if (!want_graph) {
-        r = mrgan_disc_step(h, d, 0, -1, nullptr, stream);
-        if (!r) r = mrgan_gen_step(h, g, 0, -1, nullptr, stream);
-        return r;
-    }
+    // Both sub-steps of a pair use the same generator weights (the D sub-step does not touch them), so their two
+    // generator forwards run as one two-segment pass inside the D sub-step when the G sub-step draws its z on the
+    // device and no statistic exchange sits between the generator's layers.
+    static const int pair_env = []() { const char* e = getenv("MRGAN_PAIR_GEN"); return e ? atoi(e) : 1; }();
+    auto both = [&]() {
+        h->pair_gen = (pair_env && !h->sync_stats && !g->z_dev) ? 1 : 0;
+        int rr = mrgan_disc_step(h, d, 0, -1, nullptr, stream);
+        h->pair_gen = 0;
+        if (!rr) rr = mrgan_gen_step(h, g, 0, -1, nullptr, stream);
+        h->gen_ready = 0;
+        return rr;
+    };
+    if (!want_graph) return both();
     // A pair flips the state slot twice, so every kernel argument is identical on every replay as long as
     // the slot parity and the caller's pointers are those of the capture.
     if (h->graph_ready && (h->graph_cur != h->cur || memcmp(&h->graph_d, d, sizeof *d) != 0 || memcmp(&h->graph_g, g, sizeof *g) != 0)) {
@@ -907,8 +957,7 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
         hipGraph_t graph;
         const int cur0 = h->cur;
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        r = mrgan_disc_step(h, d, 0, -1, nullptr, stream);
-        if (!r) r = mrgan_gen_step(h, g, 0, -1, nullptr, stream);
+        r = both();
         hipError_t e = hipStreamEndCapture(s, &graph);
         if (r) return r;
         if (e != hipSuccess) return fail(-10, "hipStreamEndCapture: %s", hipGetErrorString(e));

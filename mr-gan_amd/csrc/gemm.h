@@ -28,7 +28,8 @@ struct Epi {
     int n_valid;             // logical number of output columns; columns beyond are forced to zero
     const float* bias;       // FWD
     void* out; long out_bs; int ldo;            // T output [batch][rows][ldo]
-    float sigma; uint32_t site; uint32_t seg0;  // FWD: out += sigma * N(0,1) drawn at (site, seg0+batch)
+    float sigma; uint32_t site; uint32_t seg0;  // FWD: out += sigma * N(0,1) drawn at (site, seg0 + batch*seg_step, iter + batch*iter_step)
+    int seg_step; uint32_t iter_step;           // (1, 0) for the segments of one sub-step
     uint32_t row0;                              // global row offset of this rank inside a segment
     uint64_t seed;
     uint16_t* mask; long mask_bs; int ldm;      // FWD relu: written; DX relu: read. word ((row>>5)*ldm + col)*2 + half
@@ -145,7 +146,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         const T* hprev = e.h ? (const T*)e.h + (long)batch * e.h_bs : nullptr;
         const bool noisy = EPI == EPI_FWD && (DYN ? e.sigma > 0.f : (VAR & VAR_NOISE) != 0);
         uint32_t nkey = 0;
-        if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)batch, pf ? pf->iter : (e.st ? e.st->iter : 0u));
+        if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)(batch * e.seg_step),
+                                    (pf ? pf->iter : (e.st ? e.st->iter : 0u)) + (uint32_t)batch * e.iter_step);
 
 #pragma unroll
         for (int ni = 0; ni < NR; ++ni) {

@@ -299,3 +299,42 @@ def test_graph_replay_equals_eager():
         m.engine.close()
     for a, b in zip(*ws):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_pair_with_shared_generator_pass_equals_separate_substeps(dtype):
+    """mrgan_train_pair runs the two generator forwards of a (D, G) pair as one two-segment pass inside the D
+    sub-step (same generator weights; z, noise iteration and segment ids of the G sub-step).  The weights after a
+    few pairs must be bit-identical to calling the two sub-steps one after the other."""
+    from mr_gan_amd import MRGAN, engine as E
+    rs = np.random.RandomState(3)
+    B, D, n = 64, 40, 256
+    X = rs.randn(n, D).astype(np.float32)
+    xl = rs.randn(2 * B, D).astype(np.float32)
+    yl = rs.randint(0, 6, size=2 * B).astype(np.int32)
+    res = []
+    for paired in (True, False):
+        m = MRGAN(D, batch_size=B, dtype=dtype, seed=77, use_graph=False)
+        with m._on_stream():
+            xu, xlab = m._dev(X), m._dev(xl)
+            idx_lab = m._dev(np.arange(n, dtype=np.int32) % (2 * B), torch.int32)
+            labs = m._dev(yl[np.arange(n) % (2 * B)], torch.int32)
+            idx_u1 = m._dev(rs.permutation(n).astype(np.int32) if False else np.arange(n, dtype=np.int32)[::-1].copy(), torch.int32)
+            idx_u2 = m._dev(np.roll(np.arange(n, dtype=np.int32), 7), torch.int32)
+            dargs = E.Engine.disc_args(xlab, labs, xu, None, idx_lab, idx_u1, stream_mode=1)
+            gargs = E.Engine.gen_args(xu, None, idx_u2, stream_mode=1)
+            m.engine.set_iterations(0, 0)
+            for _ in range(n // B):
+                if paired:
+                    m.engine.train_pair(dargs, gargs)
+                else:
+                    m.engine.disc_step(dargs, want_outputs=False)
+                    m.engine.gen_step(gargs, want_outputs=False)
+            torch.cuda.synchronize()
+            metrics = m.engine.read_metrics(reset=True)
+        res.append((m.get_weights('discriminator') + m.get_weights('generator'), metrics))
+        m.engine.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(np.asarray(res[0][1]), np.asarray(res[1][1]))
