@@ -424,8 +424,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_fast_kernel(const G
 
 // All weight-gradient products of one sub-step in ONE launch: they have no consumer before the Adam kernel, each is
 // small (32 .. 256 blocks, 5-7 us of launch + drain per launch for 3-12 us of work), and together they fill the chip.
-// Block b works on problem i with blk_end[i-1] <= b < blk_end[i]; every count is a multiple of 8, so the block's XCD
-// (b % 8) is also its XCD inside the problem and the XCD-aware tile order of ks_fast_body stays valid.
+// Block b works on problem i with blk_end[i-1] <= b < blk_end[i].  Blocks whose index inside the problem agrees mod 8
+// still share an XCD (a constant rotation of b % 8), which is all the XCD-aware tile order of ks_fast_body relies on.
 template <int NS, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_group_kernel(const KsGroup grp) {
     int i = 0, b0 = 0;
@@ -628,7 +628,6 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
     for (int i = 0; i < n; ++i) {
         if (!ks_dense_k(gs[i])) return 1;
         const int blocks = ceil_div(gs[i].N, 128) * ceil_div(gs[i].M, 128) * gs[i].splits;
-        if (blocks % 8) return 1;
         total += blocks;
         grp.blk_end[i] = total;
         grp.g[i] = gs[i];
