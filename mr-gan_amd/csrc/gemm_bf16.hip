@@ -565,7 +565,8 @@ static int env_int(const char* name, int dflt) {
 
 // epilogue variants compiled for the bf16 path (anything else is a host-side error)
 // tile configs: 0 = 64x128 / 4 waves / 3 stages ; 1 = 128x128 / 4 waves / 2 stages ; 2 = 256x128 / 8 waves / 2 stages ;
-//               3 = 256x256 / 8 waves / 2 stages.  MRGAN_KC_CFG forces one; default picks by grid size.
+//               3 = 256x256 / 8 waves / 2 stages ; 4 = cfg 0 with pipelined fragments ; 5 = 64x128 / 4 waves / 2 stages
+//               (three blocks per CU).  MRGAN_KC_CFG forces one; default picks by grid size.
 template <int EPI, int VAR>
 static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
     static const int forced = env_int("MRGAN_KC_CFG", -1);
@@ -574,7 +575,11 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         // measured on MI355X (scripts/gemm_bench.py): bigger tiles win once they still give >= ~1.5 blocks per CU
         const int t128 = ceil_div(g.M, 128) * ceil_div(g.N, 128) * g.nbatch;
         const int t256 = ceil_div(g.M, 256) * ceil_div(g.N, 256) * g.nbatch;
-        cfg = (EPI == EPI_DX && (g.N % 256) == 0 && t256 >= 192) ? 3 : t128 >= 384 ? 1 : 0;
+        (void)t256;
+        cfg = t128 >= 384 ? 1 : 0;
+        // long reductions into a narrow output (D2 forward: K = 1024, N = 512): three 64x128 blocks per CU with a
+        // 2-stage ring hide the k-loop latency better than two 128x128 blocks (20.7 vs 21.7 us)
+        if (EPI == EPI_FWD && cfg == 1 && g.K >= 1024 && g.N <= 512) cfg = 5;
     }
     if (cfg >= 2 && (g.N % 128) != 0) cfg = 0;
     // DX epilogues that may stage a tile of e.h in LDS (softplus derivative, xhat sums) only exist for the small tiles
@@ -585,6 +590,7 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         if (cfg == 3) return (g.N % 256) == 0 ? launch_kc<EPI, 256, 256, 2, 4, 2, VAR>(g, s) : launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
     }
     if (cfg == 1) return launch_kc<EPI, 128, 128, 2, 2, 2, VAR>(g, s);
+    if (cfg == 5) return launch_kc<EPI, 64, 128, 2, 2, 2, VAR>(g, s);      // 48 KiB ring: three blocks per CU
     // cfg 4 / MRGAN_KC_PIPE=1 (launches with at most one 64x128 tile per CU): pipelined fragments, 4-stage ring.
     // Measured no faster than cfg 0 on MI355X -- these launches are bound by the L2 -> LDS fill, not by the LDS -> MFMA chain.
     static const int pipe = env_int("MRGAN_KC_PIPE", 0);
