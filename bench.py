@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--local-stats", action="store_true", help="per-shard BN / feature-matching statistics (N > 1 only)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (see mrgan_debug_ablate)")
+    ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 phase protocol (no all-reduce) on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -139,7 +140,8 @@ def main():
     cfg.dtype = E.BF16 if args.dtype == "bf16" else E.F32
     cfg.seed = 1
     cfg.rank, cfg.world = rank, world
-    cfg.flags = dp_flags(exact=not args.local_stats) if world > 1 else (0 if args.no_graph else E.FLAG_GRAPH)
+    use_dp = world > 1 or args.force_dp
+    cfg.flags = dp_flags(exact=not args.local_stats) if use_dp else (0 if args.no_graph else E.FLAG_GRAPH)
     if args.ablate:
         E.load_library().mrgan_debug_ablate(args.ablate)
     stream = torch.cuda.Stream(dev)
@@ -172,7 +174,7 @@ def main():
         dargs = E.Engine.disc_args(xld, lab_stream, Xd, None, idx_lab, idx_unl, stream_mode=1)
         gargs = E.Engine.gen_args(Xd, None, idx_unl2, stream_mode=1)
         eng.set_iterations(0, 0)
-        runner = DataParallel(EngineBackend(eng), exact=not args.local_stats) if world > 1 else None
+        runner = DataParallel(EngineBackend(eng), exact=not args.local_stats) if use_dp else None
 
         def step():
             if runner is not None:

@@ -80,7 +80,7 @@ struct FmArgs {
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s);
 
 // ---- collapse per-row-tile partial sums to one row (data-parallel statistic exchange) ----
-int launch_colsum_finalize(const float* part, int npart, int ld, int n, float* out, hipStream_t s);
+int launch_colsum_finalize(const float* part1, const float* part2, int npart, int ld, int n, float* out /* [2][n] */, hipStream_t s);
 
 // ---- multi-tensor Adam (Keras 2.0.9 formula, mr_gan.py:165-167) ----
 struct AdamTile {

@@ -447,12 +447,12 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, int npart, int ld, int n, float* out) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < npart; ++p) s += part[(long)p * ld + j];
-    out[j] = s;
+// two sets of per-row-tile partial sums -> two rows of `out` (out[0..n) and out[n..2n)); blockIdx.y picks the set
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part1, const float* part2, int npart, int ld, int n, float* out) {
+    __shared__ float scr[16][CB], res[CB];
+    const int col0 = blockIdx.x * CB;
+    fold_partials(blockIdx.y ? part2 : part1, npart, ld, col0, n, scr, res);
+    if (threadIdx.x < CB && col0 + threadIdx.x < n) out[(long)blockIdx.y * n + col0 + threadIdx.x] = res[threadIdx.x];
 }
 
 // =========================================================================================
@@ -634,8 +634,9 @@ int launch_fm(int bf16, const FmArgs& a, hipStream_t s) {
     RET_LAUNCH;
 }
 
-int launch_colsum_finalize(const float* part, int npart, int ld, int n, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, part, npart, ld, n, out);
+int launch_colsum_finalize(const float* part1, const float* part2, int npart, int ld, int n, float* out, hipStream_t s) {
+    if (n % 4) return -3;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(n, CB), 2), dim3(256), 0, s, part1, part2, npart, ld, n, out);
     RET_LAUNCH;
 }
 

@@ -520,8 +520,7 @@ int gen_fwd_head(mrgan_handle* h, int nb, hipStream_t s) {
                   true, s));
     if (h->sync_stats) {
         const int n = h->g[0].Np;
-        PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn1, h->tiles_m, n, n, h->r_bn_stats, s));
-        PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats + n, s));
+        PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn1, h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats, s));
     }
     return 0;
 }
@@ -657,8 +656,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         h->gen_ready = 0;
         CHK(disc_fwd_train(h, 2, true, h->xbase, s));
         if (h->sync_stats) {
-            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f, tm, h->Fp, h->Fp, h->r_fm, s));
-            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm + h->Fp, s));
+            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f, h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm, s));
         }
     } else if (phase == MRGAN_G_BWD) {
         FmArgs f;
@@ -680,8 +678,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         CHK(dense_dx(h, h->g[1], h->dpre2g, B, 1, h->dhbn, ACT_LINEAR, h->g[0].N, nullptr, 0, h->h1, CS_SUM_XHAT, h->cs_dbeta,
                      h->cs_dgamma, s));
         if (h->sync_stats) {
-            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_dbeta, tm, N1p, N1p, h->r_bn_bwd, s));
-            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_dgamma, tm, N1p, N1p, h->r_bn_bwd + N1p, s));
+            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_dbeta, h->cs_dgamma, tm, N1p, N1p, h->r_bn_bwd, s));
         }
     } else if (phase == MRGAN_G_TAIL) {
         BnBwdArgs b;
