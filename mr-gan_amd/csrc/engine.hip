@@ -169,11 +169,13 @@ int pad64(int x) { return (int)round_up(x, PADW); }
 
 constexpr int MAX_SLABS = 16;
 // Reduction splits (= fp32 slabs per tensor, summed by the Adam kernel) of the weight-gradient products of one
-// network.  The products of a sub-step run as ONE grouped launch (dense_dw_all), every block costs the same per
-// reduction row, so the best grid is a single round: the largest common split count with at most one block per CU.
-// Measured on MI355X (B=4096, D=512): D network 3 splits (240 blocks) 0.459 ms/step, 6 -> 0.470, 8/16 -> 0.488.
+// network.  The products of a sub-step run as ONE grouped launch (dense_dw_all) of 128x128 blocks, two of which share
+// a CU, and every block costs the same per reduction row: the best grid is a single round that fills most of the 512
+// block slots, with as few slabs as that allows (each slab is read again by Adam).
+// Measured on MI355X (B=4096, D=512, ms/step): D network 5 splits (400 blocks) 0.449, 6 -> 0.455, 4 -> 0.459, 8 -> 0.472.
 int choose_splits(int group_tiles, int vrows) {
-    int s = 256 / std::max(1, group_tiles);
+    int s = 435 / std::max(1, group_tiles);     // ~85 % of 512 slots
+    s = std::min(s, 6);
     s = std::min(s, ceil_div(vrows, 512));      // keep >= 512 reduction rows per slab
     return std::max(1, std::min(s, MAX_SLABS));
 }

@@ -638,15 +638,30 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
         grp.blk_end[i] = total;
         grp.g[i] = gs[i];
     }
-    constexpr int NS = 3, WM = 2, WN = 4, STAGE = 2 * 64 * 256;
+    // The loop is bound by the LDS: ds_read_b64_tr_b16 moves 512 B per wave-instruction, and 128x128 blocks of 8 waves
+    // (64x32 per wave) need 1.5 of them per MFMA.  Four waves of 64x64 need 1.0, and with a 2-stage ring (64 KiB) two
+    // such blocks share a CU, which keeps 8 waves per CU for latency hiding: grouped D products 63 -> ~45 us.
+    // MRGAN_KS_W8=1 selects the 8-wave / 3-stage blocks (one per CU) again.
+    constexpr int STAGE = 2 * 64 * 256;
+    static const int w8 = env_int("MRGAN_KS_W8", 0);
     static bool attr_done = false;
-    auto kern = gemm_bf16_ks_group_kernel<NS, WM, WN>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE) != hipSuccess) return -2;
-        attr_done = true;
+    if (w8) {
+        auto kern = gemm_bf16_ks_group_kernel<3, 2, 4>;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE) != hipSuccess) return -2;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(total), dim3(512), 3 * STAGE, s, grp);
+        if (kname) *kname = "gemm_bf16_ks_group_kernel<3, 2, 4>";
+    } else {
+        auto kern = gemm_bf16_ks_group_kernel<2, 2, 2>;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) return -2;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(total), dim3(256), 2 * STAGE, s, grp);
+        if (kname) *kname = "gemm_bf16_ks_group_kernel<2, 2, 2>";
     }
-    hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WM * WN), NS * STAGE, s, grp);
-    if (kname) *kname = "gemm_bf16_ks_group_kernel<3, 2, 4>";
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
