@@ -370,6 +370,23 @@ int prof_cat(mrgan_handle* h, const char* name) {
     h->prof_names.push_back(name);
     return (int)h->prof_names.size() - 1;
 }
+// Profiling pass only: a ~0.4 ms single-wave delay at the head of each sub-step.  While it runs the host enqueues
+// the sub-step's launches and event records behind it, so the intervals between consecutive events measure the
+// kernels back to back instead of the host's launch rate (which is slower than the short kernels).
+__global__ void prof_delay_kernel(int us) {
+    for (int i = 0; i < us; ++i) __builtin_amdgcn_s_sleep(36);      // 36 * 64 cycles ~ 1 us
+}
+
+void prof_mark(mrgan_handle* h, const char* name, double flops, hipStream_t s);
+void prof_backlog(mrgan_handle* h, hipStream_t s) {
+    if (!h->prof) return;
+    hipLaunchKernelGGL(prof_delay_kernel, dim3(1), dim3(64), 0, s, 400);
+    prof_mark(h, "(start)", 0, s);
+    hipEventRecord(h->prof_recs.back().ev, s);
+    prof_mark(h, "(event overhead)", 0, s);          // two records with nothing between: an upper bound of what an interval
+    hipEventRecord(h->prof_recs.back().ev, s);       // contains besides its kernel (reported, not subtracted)
+}
+
 void prof_mark(mrgan_handle* h, const char* name, double flops, hipStream_t s) {
     if (!h->prof) return;
     ProfRec r;
@@ -591,6 +608,7 @@ void data_seg(StageSeg& sg, mrgan_handle* h, const float* x, const int32_t* idx,
 int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t s) {
     const int B = h->B;
     if (phase == MRGAN_D_GEN) {
+        prof_backlog(h, s);
         StageArgs st;
         memset(&st, 0, sizeof st);
         data_seg(st.s[0], h, a->x_lab_dev, a->idx_lab_dev, a->ld_x_lab, 0, 0, a->stream_mode);
@@ -640,6 +658,7 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
 int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s) {
     const int B = h->B, tm = h->tiles_m, N1p = h->g[0].Np;
     if (phase == MRGAN_G_GEN) {
+        prof_backlog(h, s);
         StageArgs st;
         memset(&st, 0, sizeof st);
         // after a paired forward (train_pair) the fake rows already sit in slot 3 and the generator activations in
@@ -1044,7 +1063,9 @@ int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, int max_kernels, cha
         const ProfRec& r = h->prof_recs[i];
         if (i > 0 && r.cat < n && h->prof_names[r.cat] != "(start)") {
             float t = 0.f;
-            if (hipEventElapsedTime(&t, h->prof_recs[i - 1].ev, r.ev) == hipSuccess) { ms[r.cat] += t; launches[r.cat] += 1; flops[r.cat] += r.flops; }
+            if (hipEventElapsedTime(&t, h->prof_recs[i - 1].ev, r.ev) == hipSuccess) {
+                ms[r.cat] += t; launches[r.cat] += 1; flops[r.cat] += r.flops;
+            }
         }
     }
     for (auto& r : h->prof_recs) hipEventDestroy(r.ev);

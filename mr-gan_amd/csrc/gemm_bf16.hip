@@ -289,7 +289,7 @@ template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR, bool PIPE =
 int launch_kc(const GemmArgs& g, hipStream_t s) {
     static const std::string name = "gemm_bf16_kc_kernel<" + std::to_string(EPI) + ", " + std::to_string(BM) + ", " +
                                     std::to_string(BNT) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
-                                    std::to_string(NS) + ", " + std::to_string(VAR) + (PIPE ? ", true>" : ">");
+                                    std::to_string(NS) + ", " + std::to_string(VAR) + (PIPE ? ", true>" : ", false>");
     g_last_kernel = name.c_str();
     constexpr int STAGE = BM * 128 + BNT * 128;
     // staged output tile + column-sum scratch (+ the tile of e.h for the DX epilogues that read it)
