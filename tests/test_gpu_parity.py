@@ -338,3 +338,67 @@ def test_pair_with_shared_generator_pass_equals_separate_substeps(dtype):
     for a, b in zip(res[0][0], res[1][0]):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(np.asarray(res[0][1]), np.asarray(res[1][1]))
+
+
+def _dp_worker(rank, world, port, exact, q):
+    """One rank of a real 2-process data-parallel run (gloo moves the GPU regions through the host; RCCL needs
+    one GPU per rank, which the 1-GPU test box does not have)."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mr_gan_amd import engine as E
+    from mr_gan_amd.dist import DataParallel, EngineBackend, dp_flags
+    B, D, steps = 64, 32, 2
+    case = Case(D=D, B=B, steps=steps, device_z=True)
+    h = B // world
+    eng = _engine(D, h, 0, flags=dp_flags(exact), rank=rank, world=world)
+    _load(eng, case)
+    dp = DataParallel(EngineBackend(eng), exact=exact)
+    sl = slice(rank * h, (rank + 1) * h)
+    for t in range(steps):
+        dp.disc_step(E.Engine.disc_args(_t(case.x_lab[t][sl]), _t(case.labels[t][sl], torch.int32), _t(case.x_unl[t][sl])))
+        dp.gen_step(E.Engine.gen_args(_t(case.x_unl2[t][sl])))
+    torch.cuda.synchronize()
+    q.put((rank, eng.get_weights(E.NET_D), eng.get_weights(E.NET_G)))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_two_process_data_parallel_on_one_gpu(exact):
+    """mr-gan_amd/dist.py end to end with two OS processes sharing the GPU: replicas end bit-identical; with the
+    statistic exchanges (exact) they also reproduce the single-process full-batch step."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, exact, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    out, waited = [], 0.0
+    while len(out) < 2:
+        try:
+            out.append(q.get(timeout=2.0))
+        except _queue.Empty:
+            waited += 2.0
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: %s" % [p.exitcode for p in procs]
+            assert waited < 180.0, "data-parallel ranks did not finish"
+    out.sort(key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, d0, g0), (_, d1, g1) = out
+    for a, b in zip(d0 + g0, d1 + g1):
+        np.testing.assert_array_equal(a, b)
+    case = Case(D=32, B=64, steps=2, device_z=True)
+    ref = case.run_oracle()
+    errs = [update_rel_err(w, wr, wi) for w, wr, wi in zip(d0, ref['d'], case.d0)]
+    if exact:
+        assert max(errs) < 0.05, errs
+    else:
+        assert max(errs) > 1e-4            # per-shard statistics: a different (labelled) algorithm
