@@ -108,6 +108,11 @@ int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int phase_first, in
                    float* out1_host, mrgan_stream stream);
 /* one iteration of the hot loop (mr_gan.py:204-213): D step then G step */
 int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_args* g, mrgan_stream stream);
+/* For hosts that drive the phases themselves (data parallel) and know that the next mrgan_disc_step is followed by a
+ * mrgan_gen_step whose z is drawn on the device: on != 0 lets that D sub-step also run the G sub-step's generator
+ * forward as a second segment of the same launches (what mrgan_train_pair does by itself).  Ignored with
+ * MRGAN_FLAG_SYNC_STATS (a statistic exchange sits inside the generator).  Cleared by the G sub-step. */
+int mrgan_pair_hint(mrgan_handle* h, int on);
 
 /* regions a data-parallel host all-reduces (sum) between phases; fp32 */
 enum {

@@ -620,6 +620,7 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
     } else if (phase == MRGAN_D_MAIN) {
         CHK(gen_fwd_tail(h, h->pair_gen ? 2 : 1, 2, 2, s));               // fake rows -> slot 2 (+ the G sub-step's -> slot 3)
         h->gen_ready = h->pair_gen;
+        h->pair_gen = 0;                                                  // one D sub-step per hint
         CHK(disc_fwd_train(h, 3, false, 0, s));
         HeadArgs hd;
         memset(&hd, 0, sizeof hd);
@@ -994,6 +995,12 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
         h->graph_d = *d; h->graph_g = *g; h->graph_cur = cur0; h->graph_ready = true;
     }
     HIPCHK(hipGraphLaunch(h->graph_exec, s));
+    return 0;
+}
+
+int mrgan_pair_hint(mrgan_handle* h, int on) {
+    if (!h) return fail(-1, "null handle");
+    h->pair_gen = (on && !h->sync_stats) ? 1 : 0;
     return 0;
 }
 

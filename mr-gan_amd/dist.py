@@ -46,6 +46,9 @@ class EngineBackend(PhaseBackend):
     def region(self, which):
         return self.engine.region(which)
 
+    def pair_hint(self, on=True):
+        self.engine.pair_hint(on)
+
 
 class DataParallel(object):
     def __init__(self, backend, exact=True, group=None):
@@ -83,6 +86,11 @@ class DataParallel(object):
         b.gen_phase(args, E.G_ADAM)
 
     def train_pair(self, dargs, gargs):
+        # per-shard statistics: nothing is exchanged inside the generator, so the pair's two generator forwards can run
+        # as one pass inside the D sub-step (the engine ignores the hint when the G sub-step brings its own z)
+        hint = getattr(self.backend, "pair_hint", None)
+        if hint is not None and not self.exact:
+            hint(True)
         self.disc_step(dargs)
         self.gen_step(gargs)
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "mrgan_num_tensors", "mrgan_tensor_shape", "mrgan_set_weights", "mrgan_get_weights", "mrgan_get_slot",
     "mrgan_set_slot", "mrgan_get_iterations", "mrgan_set_iterations", "mrgan_disc_step", "mrgan_gen_step",
     "mrgan_train_pair", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
-    "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time",
+    "mrgan_pair_hint", "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time",
 ]
 PROF_NAME_LEN = 96
 
@@ -236,6 +236,10 @@ class Engine(object):
 
     def train_pair(self, dargs, gargs):
         _check(self.lib.mrgan_train_pair(self.handle, C.byref(dargs), C.byref(gargs), _stream()))
+
+    def pair_hint(self, on=True):
+        """the next disc_step is followed by a gen_step with device-drawn z: share the generator pass (no-op with synced statistics)"""
+        _check(self.lib.mrgan_pair_hint(self.handle, 1 if on else 0))
 
     def eval_error(self, x, labels, idx=None):
         """test_batch -> err"""

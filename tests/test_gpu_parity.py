@@ -314,7 +314,7 @@ def test_pair_with_shared_generator_pass_equals_separate_substeps(dtype):
     xl = rs.randn(2 * B, D).astype(np.float32)
     yl = rs.randint(0, 6, size=2 * B).astype(np.int32)
     res = []
-    for paired in (True, False):
+    for paired in (True, False, "hint"):
         m = MRGAN(D, batch_size=B, dtype=dtype, seed=77, use_graph=False)
         with m._on_stream():
             xu, xlab = m._dev(X), m._dev(xl)
@@ -326,18 +326,21 @@ def test_pair_with_shared_generator_pass_equals_separate_substeps(dtype):
             gargs = E.Engine.gen_args(xu, None, idx_u2, stream_mode=1)
             m.engine.set_iterations(0, 0)
             for _ in range(n // B):
-                if paired:
+                if paired is True:
                     m.engine.train_pair(dargs, gargs)
                 else:
+                    if paired == "hint":                      # what the data-parallel host does between its phases
+                        m.engine.pair_hint(True)
                     m.engine.disc_step(dargs, want_outputs=False)
                     m.engine.gen_step(gargs, want_outputs=False)
             torch.cuda.synchronize()
             metrics = m.engine.read_metrics(reset=True)
         res.append((m.get_weights('discriminator') + m.get_weights('generator'), metrics))
         m.engine.close()
-    for a, b in zip(res[0][0], res[1][0]):
-        np.testing.assert_array_equal(a, b)
-    np.testing.assert_array_equal(np.asarray(res[0][1]), np.asarray(res[1][1]))
+    for other in res[1:]:
+        for a, b in zip(res[0][0], other[0]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(np.asarray(res[0][1]), np.asarray(other[1]))
 
 
 def _dp_worker(rank, world, port, exact, q):
@@ -358,8 +361,8 @@ def _dp_worker(rank, world, port, exact, q):
     dp = DataParallel(EngineBackend(eng), exact=exact)
     sl = slice(rank * h, (rank + 1) * h)
     for t in range(steps):
-        dp.disc_step(E.Engine.disc_args(_t(case.x_lab[t][sl]), _t(case.labels[t][sl], torch.int32), _t(case.x_unl[t][sl])))
-        dp.gen_step(E.Engine.gen_args(_t(case.x_unl2[t][sl])))
+        dp.train_pair(E.Engine.disc_args(_t(case.x_lab[t][sl]), _t(case.labels[t][sl], torch.int32), _t(case.x_unl[t][sl])),
+                      E.Engine.gen_args(_t(case.x_unl2[t][sl])))
     torch.cuda.synchronize()
     q.put((rank, eng.get_weights(E.NET_D), eng.get_weights(E.NET_G)))
     dist.barrier()
