@@ -110,15 +110,14 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--sync-stats", action="store_true",
-                    help="N > 1: all-reduce the BatchNorm / feature-matching statistics too (W ranks at B/W reproduce the one-GPU "
-                         "batch-B step; 4 more small collectives per step). Default: per-shard statistics, gradients all-reduced")
-    ap.add_argument("--local-stats", action="store_true", help="(default for N > 1; kept for compatibility)")
+    ap.add_argument("--local-stats", action="store_true",
+                    help="N > 1: keep the BatchNorm / feature-matching statistics per shard (a different, labelled algorithm: 3 "
+                         "fewer small collectives per step). Default: they are all-reduced, so that W ranks at B/W reproduce the "
+                         "one-GPU batch-B step")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (see mrgan_debug_ablate)")
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 phase protocol (no all-reduce) on one GPU")
     args = ap.parse_args()
-    args.local_stats = not args.sync_stats
 
     import torch
     import torch.distributed as dist
@@ -269,8 +268,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: synthetic N=%d x D=%d, K=6, batch %d per GPU, labeled %d/class; one step = "
                                "D sub-step (3B rows) + G sub-step (2B rows) + both Adam updates" % (args.rows, D, B, args.labeled_per_class),
                    "global_batch": B * world, "parallelism": "dp%d" % world if world > 1 else "single",
-                   "batch_statistics": ("per_shard (standard data-parallel BatchNorm; --sync-stats for global-batch statistics)"
-                                        if args.local_stats else "synced over ranks") if world > 1 else "n/a",
+                   "batch_statistics": ("local_stats (per shard)" if args.local_stats else "synced over ranks") if world > 1 else "n/a",
                    "launch": "eager phases + RCCL all-reduce" if world > 1 else ("eager" if args.no_graph else "hipGraph replay")},
         "roofline": roofline,
         "train_metrics": {"mean_loss_lab": metrics[0] / args.steps, "mean_loss_unl": metrics[1] / args.steps,

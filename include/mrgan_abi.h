@@ -110,13 +110,15 @@ int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int phase_first, in
 int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_args* g, mrgan_stream stream);
 /* For hosts that drive the phases themselves (data parallel) and know that the next mrgan_disc_step is followed by a
  * mrgan_gen_step whose z is drawn on the device: on != 0 lets that D sub-step also run the G sub-step's generator
- * forward as a second segment of the same launches (what mrgan_train_pair does by itself).  Ignored with
- * MRGAN_FLAG_SYNC_STATS (a statistic exchange sits inside the generator).  Cleared by the G sub-step. */
+ * forward as a second segment of the same launches (what mrgan_train_pair does by itself).  With
+ * MRGAN_FLAG_SYNC_STATS the BN_STATS region then holds both segments and ONE all-reduce after D_GEN serves both
+ * sub-steps: the host skips the exchange after that G sub-step's G_GEN.  One D sub-step per hint. */
 int mrgan_pair_hint(mrgan_handle* h, int on);
 
 /* regions a data-parallel host all-reduces (sum) between phases; fp32 */
 enum {
-    MRGAN_REGION_BN_STATS = 0,   /* after *_GEN : [2][N1p]  sum h, sum h^2 of the generator BatchNorm input      */
+    MRGAN_REGION_BN_STATS = 0,   /* after *_GEN : [2 segments][2][N1p]  sum h, sum h^2 of the generator BatchNorm
+                                  * input; segment 1 carries the G sub-step's batch after mrgan_pair_hint            */
     MRGAN_REGION_FM_MOMENTS = 1, /* after G_FEAT: [2][Fp]   sum_b f(fake), sum_b f(real)                         */
     MRGAN_REGION_BN_BWD = 2,     /* after G_BWD : [2][N1p]  sum dy, sum dy*xhat                                  */
     MRGAN_REGION_GRAD_D = 3,     /* after D_MAIN: flat padded gradients of the 12 D tensors + 4 scalars          */

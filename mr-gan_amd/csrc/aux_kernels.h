@@ -32,6 +32,7 @@ struct BnApplyArgs {
     float count, eps;                                          // global batch size
     const float* gamma; const float* beta;
     float* mu; float* rstd;                                    // saved for the backward pass
+    long cs_seg_stride;                                        // floats between the partial sums of consecutive segments
     int nseg; long seg_rows;                                   // nseg independent batches, seg_rows rows apart in h / out; their
                                                                // partial sums follow each other (npart rows each), mu / rstd ld apart
 };

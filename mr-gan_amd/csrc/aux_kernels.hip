@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
     __shared__ float sc[CB], sh[CB];
     __shared__ float scr[16][CB], f1[CB], f2[CB];
     const int t = threadIdx.x, col0 = blockIdx.x * CB, seg = blockIdx.z;
-    fold_partials(a.cs1 + (long)seg * a.npart * a.ldcs, a.npart, a.ldcs, col0, a.ld, scr, f1);
-    fold_partials(a.cs2 + (long)seg * a.npart * a.ldcs, a.npart, a.ldcs, col0, a.ld, scr, f2);
+    fold_partials(a.cs1 + (long)seg * a.cs_seg_stride, a.npart, a.ldcs, col0, a.ld, scr, f1);
+    fold_partials(a.cs2 + (long)seg * a.cs_seg_stride, a.npart, a.ldcs, col0, a.ld, scr, f2);
     if (t < CB) {
         const int col = col0 + t;
         float scale = 0.f, shift = 0.f;

@@ -255,7 +255,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     flat(h->gt, h->flat_g, h->flat_g_n);
     flat(h->dt, h->flat_d, h->flat_d_n);
     const int N1p = h->g[0].Np;
-    h->r_bn_stats = a.take<float>(2 * N1p);
+    h->r_bn_stats = a.take<float>(4 * N1p);                 // [segment][sum h | sum h^2][N1p]
     h->r_fm = a.take<float>(2 * h->Fp);
     h->r_bn_bwd = a.take<float>(2 * N1p);
     h->bn_mu_all = a.take<float>(2 * N1p);
@@ -539,7 +539,10 @@ int gen_fwd_head(mrgan_handle* h, int nb, hipStream_t s) {
                   true, s));
     if (h->sync_stats) {
         const int n = h->g[0].Np;
-        PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn1, h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats, s));
+        for (int sg = 0; sg < nb; ++sg) {
+            const size_t o = (size_t)sg * h->tiles_m * n;
+            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn1 + o, h->cs_bn2 + o, h->tiles_m, n, n, h->r_bn_stats + (size_t)sg * 2 * n, s));
+        }
     }
     return 0;
 }
@@ -549,8 +552,8 @@ int gen_fwd_tail(mrgan_handle* h, int nb, int fake_seg_slot, uint32_t fake_seg_i
     memset(&b, 0, sizeof b);
     b.h = h->h1; b.out = h->hbn; b.ld = n; b.rows = h->B; b.cols = h->g[0].N;
     b.nseg = nb; b.seg_rows = h->S;
-    if (h->sync_stats) { b.cs1 = h->r_bn_stats; b.cs2 = h->r_bn_stats + n; b.npart = 1; }
-    else { b.cs1 = h->cs_bn1; b.cs2 = h->cs_bn2; b.npart = h->tiles_m; }
+    if (h->sync_stats) { b.cs1 = h->r_bn_stats; b.cs2 = h->r_bn_stats + n; b.npart = 1; b.cs_seg_stride = 2 * n; }
+    else { b.cs1 = h->cs_bn1; b.cs2 = h->cs_bn2; b.npart = h->tiles_m; b.cs_seg_stride = (long)h->tiles_m * n; }
     b.ldcs = n; b.count = h->stat_count; b.eps = h->cfg.bn_eps;
     b.gamma = h->gt[2].p; b.beta = h->gt[3].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
     PROF("bn_apply_kernel", launch_bn_apply(h->bf16, b, s));
@@ -1000,7 +1003,7 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
 
 int mrgan_pair_hint(mrgan_handle* h, int on) {
     if (!h) return fail(-1, "null handle");
-    h->pair_gen = (on && !h->sync_stats) ? 1 : 0;
+    h->pair_gen = on ? 1 : 0;
     return 0;
 }
 
@@ -1008,7 +1011,7 @@ int mrgan_region(mrgan_handle* h, int region, void** ptr, size_t* bytes) {
     if (!h || !ptr || !bytes) return fail(-1, "null argument");
     const size_t n1 = (size_t)h->g[0].Np;
     switch (region) {
-        case MRGAN_REGION_BN_STATS: *ptr = h->r_bn_stats; *bytes = 2 * n1 * 4; break;
+        case MRGAN_REGION_BN_STATS: *ptr = h->r_bn_stats; *bytes = 4 * n1 * 4; break;
         case MRGAN_REGION_FM_MOMENTS: *ptr = h->r_fm; *bytes = 2 * (size_t)h->Fp * 4; break;
         case MRGAN_REGION_BN_BWD: *ptr = h->r_bn_bwd; *bytes = 2 * n1 * 4; break;
         case MRGAN_REGION_GRAD_D: *ptr = h->flat_d; *bytes = (h->flat_d_n + 4) * 4; break;

@@ -11,8 +11,8 @@ to summation order.  exact=False keeps them per-shard (a different, cheaper algo
 "local_stats" wherever it is reported).
 
 Exchanges per (D, G) pair, all sums of fp32 buffers that live inside the library workspace:
-    D: [BN stats 2xN1p]  ->  flat D gradients (+4 scalars)
-    G: [BN stats]  [FM moments 2xFp]  [BN-backward sums 2xN1p]  ->  flat G gradients (+4 scalars)
+    D: [BN stats, both sub-steps' segments]  ->  flat D gradients (+4 scalars)
+    G: [BN stats, only if not already exchanged]  [FM moments 2xFp]  [BN-backward sums 2xN1p]  ->  flat G gradients (+4 scalars)
 """
 import torch.distributed as dist
 
@@ -70,10 +70,10 @@ class DataParallel(object):
         self._allreduce(E.REGION_GRAD_D)
         b.disc_phase(args, E.D_ADAM)
 
-    def gen_step(self, args):
+    def gen_step(self, args, stats_done=False):
         b = self.backend
         b.gen_phase(args, E.G_GEN)
-        if self.exact:
+        if self.exact and not stats_done:
             self._allreduce(E.REGION_BN_STATS)
         b.gen_phase(args, E.G_FEAT)
         if self.exact:
@@ -86,13 +86,16 @@ class DataParallel(object):
         b.gen_phase(args, E.G_ADAM)
 
     def train_pair(self, dargs, gargs):
-        # per-shard statistics: nothing is exchanged inside the generator, so the pair's two generator forwards can run
-        # as one pass inside the D sub-step (the engine ignores the hint when the G sub-step brings its own z)
+        # Both sub-steps use the same generator weights, so the engine can run their two generator forwards as one
+        # two-segment pass inside the D sub-step.  In exact mode the BatchNorm statistics of both segments then travel in
+        # the D sub-step's one BN_STATS all-reduce and the G sub-step needs none.  Only when the G sub-step draws its z on
+        # the device (the engine could not know a host-supplied z in advance).
         hint = getattr(self.backend, "pair_hint", None)
-        if hint is not None and not self.exact:
+        paired = hint is not None and not getattr(gargs, "z", None)
+        if paired:
             hint(True)
         self.disc_step(dargs)
-        self.gen_step(gargs)
+        self.gen_step(gargs, stats_done=paired)
 
 
 def dp_flags(exact=True):
