@@ -102,7 +102,7 @@ def _run_engine(eng, case, device_z=False):
     return out
 
 
-@pytest.mark.parametrize("D,B", [(16, 50), (400, 50), (72, 132)])
+@pytest.mark.parametrize("D,B", [(16, 50), (400, 50), (72, 132), (800, 256)])     # (800, .) = force-only modality (config 4)
 def test_fp32_steps_match_oracle(D, B):
     case = Case(D=D, B=B, steps=3)
     ref = case.run_oracle()
@@ -195,12 +195,16 @@ def test_bf16_steps_track_oracle():
     eng.close()
 
 
-def test_bf16_gradients_track_oracle():
+@pytest.mark.parametrize("D,B", [(400, 256),      # reference-sized input, several row tiles
+                                 (3632, 512),     # all three modalities fused, one rank's shard of batch 4096
+                                 (2432, 1024),    # config 4: contact-mic log-mel only
+                                 (512, 4096)])    # config 2: the bench workload at full size
+def test_bf16_gradients_track_oracle(D, B):
     from mr_gan_amd import engine as E
-    case = Case(D=400, B=256, steps=1)
+    case = Case(D=D, B=B, steps=1)
     orc = O.MRGANOracle(case.g0, case.d0)
     _, gd, _ = orc.disc_grads(**case.disc_inputs(0, 0))
-    eng = _engine(400, 256, 1, flags=E.FLAG_FLAT_GRADS)
+    eng = _engine(D, B, 1, flags=E.FLAG_FLAT_GRADS)
     _load(eng, case)
     da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]), _t(case.z1[0]))
     eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
