@@ -225,7 +225,6 @@ def main():
     # dominant kernel = the GEMM kernel instantiation with the largest share of device time in the profiled pass;
     # its algorithmic FLOPs per launch come from the library (2 x logical M*N*K of each dense-layer product)
     P = float(args.profile_steps)
-    ev_overhead = prof.pop("(event overhead)", None)      # empty record-to-record interval (not subtracted)
     gemms = {k: v for k, v in prof.items() if k.startswith("gemm_")}
     dom = max(gemms, key=lambda k: gemms[k][0])
     dom_ms, dom_launches, dom_flops = gemms[dom]
@@ -247,10 +246,8 @@ def main():
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
         "traffic": traffic,
         "kernel": dom, "launches_per_step": dom_launches / P,
-        "timing": "hipEvent records after every launch on the launch stream, issued behind a 0.4 ms delay kernel so that the "
-                  "intervals are device-bound; an interval = kernel + event handling (about 3 us more than rocprofv3's kernel-only "
-                  "average; two records with nothing between are %.1f us apart)"
-                  % (1e3 * ev_overhead[0] / max(ev_overhead[1], 1) if ev_overhead else 0.0),
+        "timing": "hipEvent (start, stop) pairs stamped at each kernel's begin and end on the launch stream "
+                  "(hipExtLaunchKernelGGL inside the library), profiled pass of %d steps after the timed region" % args.profile_steps,
         "avg_launch_us": round(1e6 * per_launch_s, 2), "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3),
         "all_gemm_kernels": {"achieved": round(gemm_flops / (1e-3 * gemm_ms) / 1e12, 2), "ms_per_step": round(gemm_ms, 4),
                              "algorithmic_gflop_per_step": round(gemm_flops / 1e9, 2)},

@@ -140,9 +140,10 @@ int mrgan_predict_logits(mrgan_handle* h, const float* x_dev, const int32_t* idx
  * last loss_gen.  reset != 0 zeroes the sums afterwards. */
 int mrgan_read_metrics(mrgan_handle* h, float* out8_host, int reset, mrgan_stream stream);
 
-/* Per-launch timing with hipEvents recorded on the launch stream (bench.py's live roofline figure): one event
- * behind every launch, a launch is charged the interval since the previous event (kernel + the dependent-launch
- * gap in front of it).  While profiling is on, mrgan_train_pair launches eagerly (no graph replay).
+/* Per-kernel timing with hipEvents on the launch stream (bench.py's live roofline figure): while profiling is on,
+ * every kernel of the step is launched with a (start, stop) event pair stamped at its own begin and end on the device
+ * (hipExtLaunchKernelGGL), i.e. the interval rocprofv3's kernel trace reports; mrgan_train_pair launches eagerly
+ * (no graph replay) behind a short delay kernel per sub-step so that the kernels still run back to back.
  * mrgan_profile_end returns, per distinct kernel instantiation (named as rocprofv3 prints it, MRGAN_PROF_NAME_LEN
  * bytes each): summed time, launch count and summed ALGORITHMIC flops (2 x logical M*N*K of the dense layer). */
 enum { MRGAN_PROF_NAME_LEN = 96 };

@@ -579,8 +579,8 @@ __global__ void noise_debug_kernel(uint64_t seed, uint32_t site, uint32_t seg, u
 
 #define LAUNCH_T(kern, grid, block, smem, s, args)                                  \
     do {                                                                            \
-        if (bf16) hipLaunchKernelGGL(kern<__bf16>, grid, block, smem, s, args);     \
-        else hipLaunchKernelGGL(kern<float>, grid, block, smem, s, args);           \
+        if (bf16) MRGAN_LAUNCH(kern<__bf16>, grid, block, smem, s, args);     \
+        else MRGAN_LAUNCH(kern<float>, grid, block, smem, s, args);           \
     } while (0)
 #define RET_LAUNCH return hipGetLastError() == hipSuccess ? 0 : -2
 
@@ -623,7 +623,7 @@ int launch_head(int bf16, const HeadArgs& a, hipStream_t s) {
 }
 
 int launch_reduce_partials(const float* src, int nsrc, long stride, int n, int ngroups, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ceil_div(n, 256), ngroups), dim3(256), 0, s, src, nsrc, stride, n, ngroups, dst);
+    MRGAN_LAUNCH(reduce_partials_kernel, dim3(ceil_div(n, 256), ngroups), dim3(256), 0, s, src, nsrc, stride, n, ngroups, dst);
     RET_LAUNCH;
 }
 
@@ -636,18 +636,18 @@ int launch_fm(int bf16, const FmArgs& a, hipStream_t s) {
 
 int launch_colsum_finalize(const float* part1, const float* part2, int npart, int ld, int n, float* out, hipStream_t s) {
     if (n % 4) return -3;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(n, CB), 2), dim3(256), 0, s, part1, part2, npart, ld, n, out);
+    MRGAN_LAUNCH(colsum_finalize_kernel, dim3(ceil_div(n, CB), 2), dim3(256), 0, s, part1, part2, npart, ld, n, out);
     RET_LAUNCH;
 }
 
 int launch_adam(const AdamArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(adam_kernel, dim3(a.ntiles + 1), dim3(256), 0, s, a);
+    MRGAN_LAUNCH(adam_kernel, dim3(a.ntiles + 1), dim3(256), 0, s, a);
     RET_LAUNCH;
 }
 
 int launch_noise_debug(uint64_t seed, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,
                        float* out, hipStream_t s) {
-    hipLaunchKernelGGL(noise_debug_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 4)), dim3(64), 0, s, seed, site, seg,
+    MRGAN_LAUNCH(noise_debug_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 4)), dim3(64), 0, s, seed, site, seg,
                        step, row0, rows, cols, out);
     RET_LAUNCH;
 }

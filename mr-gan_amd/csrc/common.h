@@ -1,9 +1,25 @@
 // Shared device/host definitions for libmrgan_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace mrgan {
+
+// Every kernel of the step is launched through MRGAN_LAUNCH.  Normally that is hipLaunchKernelGGL; while the library's
+// profiling pass has armed the timer, the launch goes through hipExtLaunchKernelGGL with a (start, stop) event pair,
+// whose timestamps are taken at the kernel's own begin and end on the device -- the same interval rocprofv3's
+// kernel trace reports, with no launch gap or event-handling time in it.
+struct LaunchTimer { hipEvent_t start, stop; int armed, fired; };
+extern thread_local LaunchTimer g_launch_timer;
+#define MRGAN_LAUNCH(kern, grid, block, lds, stream, ...)                                                             \
+    do {                                                                                                               \
+        ::mrgan::LaunchTimer& lt_ = ::mrgan::g_launch_timer;                                                           \
+        if (lt_.armed) {                                                                                               \
+            lt_.armed = 0; lt_.fired = 1;                                                                              \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, lt_.start, lt_.stop, 0, __VA_ARGS__);                \
+        } else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                        \
+    } while (0)
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

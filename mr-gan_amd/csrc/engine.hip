@@ -16,6 +16,7 @@
 using namespace mrgan;
 
 namespace mrgan {
+thread_local LaunchTimer g_launch_timer = {nullptr, nullptr, 0, 0};      // see MRGAN_LAUNCH (common.h)
 int launch_tr_probe(unsigned short* out, hipStream_t s);
 }
 
@@ -61,7 +62,7 @@ struct Dense {
     float* slabs; int splits;   // weight-gradient slabs [nseg*splits][Kp][Np]
 };
 
-struct ProfRec { int cat; hipEvent_t ev; double flops; };      // ev = recorded after the launch; start = previous record's ev
+struct ProfRec { int cat; hipEvent_t start, stop; double flops; };      // device-side begin / end of one kernel (MRGAN_LAUNCH)
 
 struct Arena {
     char* base = nullptr; size_t off = 0, cap = 0;
@@ -362,8 +363,8 @@ int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n,
 // ------------------------------------------------------------------------------------------------
 // optional per-launch timing: one hipEvent pair per launch, on the launch stream
 // ------------------------------------------------------------------------------------------------
-// One event per launch, recorded behind it; a launch's time is the interval since the previous event on the
-// stream, i.e. kernel time plus the dependent-launch gap in front of it (what a step really pays).
+// Per-kernel timing of the profiling pass: every launch of the step goes through MRGAN_LAUNCH (common.h), which takes
+// a (start, stop) event pair stamped at the kernel's own begin and end on the device.
 int prof_cat(mrgan_handle* h, const char* name) {
     for (size_t i = 0; i < h->prof_names.size(); ++i)
         if (h->prof_names[i] == name) return (int)i;
@@ -371,35 +372,40 @@ int prof_cat(mrgan_handle* h, const char* name) {
     return (int)h->prof_names.size() - 1;
 }
 // Profiling pass only: a ~0.4 ms single-wave delay at the head of each sub-step.  While it runs the host enqueues
-// the sub-step's launches and event records behind it, so the intervals between consecutive events measure the
-// kernels back to back instead of the host's launch rate (which is slower than the short kernels).
+// the sub-step's launches behind it, so the kernels execute back to back as they do in the graph replay (caches and
+// clocks in the same state) instead of at the host's launch rate.
 __global__ void prof_delay_kernel(int us) {
     for (int i = 0; i < us; ++i) __builtin_amdgcn_s_sleep(36);      // 36 * 64 cycles ~ 1 us
 }
 
-void prof_mark(mrgan_handle* h, const char* name, double flops, hipStream_t s);
+
 void prof_backlog(mrgan_handle* h, hipStream_t s) {
     if (!h->prof) return;
     hipLaunchKernelGGL(prof_delay_kernel, dim3(1), dim3(64), 0, s, 400);
-    prof_mark(h, "(start)", 0, s);
-    hipEventRecord(h->prof_recs.back().ev, s);
-    prof_mark(h, "(event overhead)", 0, s);          // two records with nothing between: an upper bound of what an interval
-    hipEventRecord(h->prof_recs.back().ev, s);       // contains besides its kernel (reported, not subtracted)
 }
-
-void prof_mark(mrgan_handle* h, const char* name, double flops, hipStream_t s) {
+// arm the launch timer for the next MRGAN_LAUNCH ...
+void prof_arm(mrgan_handle* h) {
     if (!h->prof) return;
-    ProfRec r;
-    r.cat = prof_cat(h, name); r.flops = flops;
-    if (hipEventCreate(&r.ev) != hipSuccess) return;
-    h->prof_recs.push_back(r);
-    if (r.cat == prof_cat(h, "(start)")) hipEventRecord(r.ev, s);
+    LaunchTimer& lt = g_launch_timer;
+    lt.armed = lt.fired = 0;
+    if (hipEventCreate(&lt.start) != hipSuccess) return;
+    if (hipEventCreate(&lt.stop) != hipSuccess) { hipEventDestroy(lt.start); return; }
+    lt.armed = 1;
 }
-#define PROF(name, call)                                                     \
-    do {                                                                     \
-        if (h->prof && h->prof_recs.empty()) prof_mark(h, "(start)", 0, s);  \
-        CHK(call);                                                           \
-        if (h->prof) { prof_mark(h, name, 0, s); hipEventRecord(h->prof_recs.back().ev, s); } \
+// ... and book the launch it timed under `name`
+void prof_done(mrgan_handle* h, const char* name, double flops) {
+    if (!h->prof) return;
+    LaunchTimer& lt = g_launch_timer;
+    if (lt.fired) h->prof_recs.push_back(ProfRec{prof_cat(h, name), lt.start, lt.stop, flops});
+    else if (lt.armed) { hipEventDestroy(lt.start); hipEventDestroy(lt.stop); }
+    lt.armed = lt.fired = 0;
+}
+#define PROF(name, call)            \
+    do {                            \
+        prof_arm(h);                \
+        const int prc_ = (call);    \
+        prof_done(h, name, 0);      \
+        CHK(prc_);                  \
     } while (0)
 
 // ------------------------------------------------------------------------------------------------
@@ -407,9 +413,10 @@ void prof_mark(mrgan_handle* h, const char* name, double flops, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 int run_gemm(mrgan_handle* h, int epi, const GemmArgs& g, double algo_flops, hipStream_t s) {
     const char* kname = "gemm";
-    if (h->prof && h->prof_recs.empty()) prof_mark(h, "(start)", 0, s);
-    CHK(h->bf16 ? launch_gemm_bf16(epi, g, s, &kname) : launch_gemm_f32(epi, g, s, &kname));
-    if (h->prof) { prof_mark(h, kname, algo_flops, s); hipEventRecord(h->prof_recs.back().ev, s); }
+    prof_arm(h);
+    const int r = h->bf16 ? launch_gemm_bf16(epi, g, s, &kname) : launch_gemm_f32(epi, g, s, &kname);
+    prof_done(h, kname, algo_flops);
+    CHK(r);
     return 0;
 }
 
@@ -490,13 +497,11 @@ int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, 
     for (int i = 0; i < n; ++i) { fl[i] = dw_args(h, gs[i], *jobs[i].L, jobs[i].x, jobs[i].dy, rows, nseg); total += fl[i]; }
     if (h->bf16) {
         const char* kname = "gemm";
-        if (h->prof && h->prof_recs.empty()) prof_mark(h, "(start)", 0, s);
+        prof_arm(h);
         const int r = launch_gemm_bf16_dw_group(gs, n, s, &kname);
+        prof_done(h, kname, total);
         if (r < 0) return fail(r, "grouped weight-gradient launch failed");
-        if (r == 0) {
-            if (h->prof) { prof_mark(h, kname, total, s); hipEventRecord(h->prof_recs.back().ev, s); }
-            return 0;
-        }
+        if (r == 0) return 0;
     }
     for (int i = 0; i < n; ++i) CHK(run_gemm(h, EPI_SLAB, gs[i], fl[i], s));
     return 0;
@@ -1069,16 +1074,11 @@ int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, int max_kernels, cha
         ms[i] = 0.f; launches[i] = 0; flops[i] = 0.0;
         snprintf(names + (size_t)i * MRGAN_PROF_NAME_LEN, MRGAN_PROF_NAME_LEN, "%s", h->prof_names[i].c_str());
     }
-    for (size_t i = 0; i < h->prof_recs.size(); ++i) {
-        const ProfRec& r = h->prof_recs[i];
-        if (i > 0 && r.cat < n && h->prof_names[r.cat] != "(start)") {
-            float t = 0.f;
-            if (hipEventElapsedTime(&t, h->prof_recs[i - 1].ev, r.ev) == hipSuccess) {
-                ms[r.cat] += t; launches[r.cat] += 1; flops[r.cat] += r.flops;
-            }
-        }
+    for (const ProfRec& r : h->prof_recs) {
+        float t = 0.f;
+        if (r.cat < n && hipEventElapsedTime(&t, r.start, r.stop) == hipSuccess) { ms[r.cat] += t; launches[r.cat] += 1; flops[r.cat] += r.flops; }
     }
-    for (auto& r : h->prof_recs) hipEventDestroy(r.ev);
+    for (auto& r : h->prof_recs) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
     h->prof_recs.clear(); h->prof_names.clear();
     h->prof = false;
     *n_kernels = n;

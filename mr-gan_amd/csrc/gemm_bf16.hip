@@ -306,7 +306,7 @@ int launch_kc(const GemmArgs& g, hipStream_t s) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch;
     const int per_cu = std::max(1, (160 * 1024) / LDS);
     dim3 grid(std::min(tiles, 256 * per_cu));
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, s, g);
+    MRGAN_LAUNCH(kern, grid, dim3(64 * WM * WN), LDS, s, g);
     return 0;
 }
 
@@ -447,7 +447,7 @@ int launch_ks_fast(const GemmArgs& g, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid(ceil_div(g.N, 128) * ceil_div(g.M, 128) * g.splits);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), NS * STAGE, s, g);
+    MRGAN_LAUNCH(kern, grid, dim3(64 * WM * WN), NS * STAGE, s, g);
     return 0;
 }
 
@@ -651,7 +651,7 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE) != hipSuccess) return -2;
             attr_done = true;
         }
-        hipLaunchKernelGGL(kern, dim3(total), dim3(512), 3 * STAGE, s, grp);
+        MRGAN_LAUNCH(kern, dim3(total), dim3(512), 3 * STAGE, s, grp);
         if (kname) *kname = "gemm_bf16_ks_group_kernel<3, 2, 4>";
     } else {
         auto kern = gemm_bf16_ks_group_kernel<2, 2, 2>;
@@ -659,7 +659,7 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) return -2;
             attr_done = true;
         }
-        hipLaunchKernelGGL(kern, dim3(total), dim3(256), 2 * STAGE, s, grp);
+        MRGAN_LAUNCH(kern, dim3(total), dim3(256), 2 * STAGE, s, grp);
         if (kname) *kname = "gemm_bf16_ks_group_kernel<2, 2, 2>";
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -678,7 +678,7 @@ int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kna
             r = cfg == 0 ? launch_ks_fast<3, 2, 2>(g, s) : cfg == 1 ? launch_ks_fast<3, 2, 4>(g, s) : launch_ks_fast<4, 2, 4>(g, s);
         } else {
             dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, 128), g.nbatch * g.splits);
-            hipLaunchKernelGGL(gemm_bf16_ks_kernel, grid, dim3(256), 0, s, g);
+            MRGAN_LAUNCH(gemm_bf16_ks_kernel, grid, dim3(256), 0, s, g);
             g_last_kernel = "gemm_bf16_ks_kernel";
         }
     } else {
@@ -692,7 +692,7 @@ int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kna
 }
 
 int launch_tr_probe(unsigned short* out, hipStream_t s) {
-    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, s, out);
+    MRGAN_LAUNCH(tr_probe_kernel, dim3(1), dim3(64), 0, s, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

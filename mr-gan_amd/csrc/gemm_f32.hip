@@ -98,9 +98,9 @@ int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s, const char** knam
     dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), g.nbatch * g.splits);
     dim3 block(256);
     switch (epi) {
-        case EPI_FWD:  hipLaunchKernelGGL(gemm_f32_kernel<EPI_FWD>, grid, block, 0, s, g); break;
-        case EPI_DX:   hipLaunchKernelGGL(gemm_f32_kernel<EPI_DX>, grid, block, 0, s, g); break;
-        case EPI_SLAB: hipLaunchKernelGGL(gemm_f32_kernel<EPI_SLAB>, grid, block, 0, s, g); break;
+        case EPI_FWD:  MRGAN_LAUNCH(gemm_f32_kernel<EPI_FWD>, grid, block, 0, s, g); break;
+        case EPI_DX:   MRGAN_LAUNCH(gemm_f32_kernel<EPI_DX>, grid, block, 0, s, g); break;
+        case EPI_SLAB: MRGAN_LAUNCH(gemm_f32_kernel<EPI_SLAB>, grid, block, 0, s, g); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
