@@ -5,6 +5,7 @@
     dataset(modalities=0, forcetempTime=4, contactmicTime=0.2, leaveObjectOut=False, verbose=False)
         same signature as mr_gan.py:23
     python -m mr_gan_amd.mr_gan --tables 1 3 5 6 [-v]        (mr_gan.py:236-341)
+    python -m mr_gan_amd.mr_gan --tables 1 --gpus 8 --jobs-per-gpu 2     run-level scheduling of table 1 (scheduler.py)
 
 Extra keyword arguments (batch_size, dtype, seed, device) default to the reference's literals.
 """
@@ -129,16 +130,56 @@ def _kfold(X, y, run, verbose):
     return errors
 
 
-def main(argv=None, dataset_fn=dataset, mr_gan_fn=mr_gan):
+def _kfold_jobs(X, y, key, **job_kw):
+    """The six stratified folds of _kfold as scheduler jobs (row indices into the dataset already shipped as `key`)."""
+    from sklearn.model_selection import StratifiedKFold
+    skf = StratifiedKFold(n_splits=6, shuffle=True)              # mr_gan.py:255
+    return [dict(dataset=key, train_idx=tr, test_idx=te, **job_kw) for tr, te in skf.split(X, y)]
+
+
+def _print_kfold(errors):
+    for e in errors:
+        print('Test error:', e, 'Test accuracy:', 1.0 - e)
+    print('Average error:', np.mean(errors), 'Average accuracy:', np.mean(1.0 - np.array(errors)))
+    sys.stdout.flush()
+
+
+def _table1_scheduled(sched, dataset_fn, kw):
+    """Table 1 with the 42 trainings of a modality (7 label fractions x 6 folds) dispatched together; prints the
+    reference's lines in the reference's order (mr_gan.py:244-261)."""
+    print('\n', '-' * 25, 'Testing various amounts of labeled training data', '-' * 25)
+    print('-' * 100)
+    percents = [1, 2, 4, 8, 16, 50, 100]
+    for modality in range(len(MODALITIES)):
+        print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
+        X, y = dataset_fn(modalities=modality)
+        key = sched.put_dataset(X, y)
+        jobs = []
+        for percent in percents:
+            jobs += _kfold_jobs(X, y, key, percentlabeled=percent, **kw)
+        errors = sched.run(jobs)
+        for i, percent in enumerate(percents):
+            print('-' * 15, 'Percentage of training data labeled: %d%%' % percent, '-' * 15)
+            _print_kfold(errors[6 * i:6 * i + 6])
+
+
+def main(argv=None, dataset_fn=dataset, mr_gan_fn=mr_gan, scheduler_factory=None):
     parser = argparse.ArgumentParser(description='Semi-supervised learning with GANs for material recognition on haptic data.')
     parser.add_argument('-t', '--tables', nargs='+', help='[Required] Tables to recompute', required=True)
     parser.add_argument('-v', '--verbose', help='Verbose', action='store_true')
     parser.add_argument('--epochs', type=int, default=100)
     parser.add_argument('--dtype', default='float32')
+    parser.add_argument('--gpus', type=int, default=0,
+                        help='run-level scheduling (table 1): dispatch the independent trainings over this many GPUs (0 = in-process, sequential)')
+    parser.add_argument('--jobs-per-gpu', type=int, default=1, help='concurrent trainings per GPU with --gpus')
     args = parser.parse_args(argv)
     kw = dict(epochs=args.epochs, dtype=args.dtype, verbose=args.verbose)
 
-    if '1' in args.tables:                                         # mr_gan.py:244-261
+    if '1' in args.tables and args.gpus > 0:                       # same table, trainings dispatched by the scheduler
+        from mr_gan_amd.scheduler import RunScheduler
+        with (scheduler_factory or RunScheduler)(gpus=args.gpus, jobs_per_gpu=args.jobs_per_gpu) as sched:
+            _table1_scheduled(sched, dataset_fn, dict(epochs=args.epochs, dtype=args.dtype))
+    elif '1' in args.tables:                                       # mr_gan.py:244-261
         print('\n', '-' * 25, 'Testing various amounts of labeled training data', '-' * 25)
         print('-' * 100)
         for modality in range(len(MODALITIES)):

@@ -99,3 +99,15 @@ def frob_rel_err(a, ref):
 def cosine(a, ref):
     a, ref = np.asarray(a, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
     return float(a @ ref / (np.linalg.norm(a) * np.linalg.norm(ref) + 1e-300))
+
+
+def stub_training(job, datasets, device):
+    """CPU stand-in for scheduler.train_job: a deterministic 'test error' from the job's rows (and the worker's pid, so
+    tests can see that several processes took part)."""
+    import os
+    X, y = datasets[job['dataset']]
+    tr, te = job['train_idx'], job['test_idx']
+    val = float(np.mean(X[tr]) - np.mean(X[te]) + 0.01 * job.get('percentlabeled', 0) + np.mean(y[te]))
+    if job.get('explode'):
+        raise ValueError("stub failure requested")
+    return (val, os.getpid(), device)

@@ -409,3 +409,24 @@ def test_two_process_data_parallel_on_one_gpu(exact):
         assert max(errs) < 0.05, errs
     else:
         assert max(errs) > 1e-4            # per-shard statistics: a different (labelled) algorithm
+
+
+def test_run_scheduler_trains_concurrently_on_one_gpu():
+    """scheduler.RunScheduler with two worker processes on cuda:0: four seeded mr_gan() trainings come back in job order and
+    equal the same trainings run one after the other in this process."""
+    from mr_gan_amd import synthetic_blobs
+    from mr_gan_amd.mr_gan import mr_gan
+    from mr_gan_amd.scheduler import RunScheduler
+    X, y = synthetic_blobs(n=720, d=24, seed=5)
+    rs = np.random.RandomState(0)
+    jobs = []
+    for i in range(4):
+        perm = rs.permutation(720)
+        jobs.append(dict(train_idx=perm[:600], test_idx=perm[600:], percentlabeled=4, epochs=2, seed=100 + i))
+    want = [mr_gan(None, None, trainTestSets=[X[j['train_idx']], X[j['test_idx']], y[j['train_idx']], y[j['test_idx']]],
+                   percentlabeled=4, epochs=2, seed=j["seed"]) for j in jobs]
+    with RunScheduler(gpus=1, jobs_per_gpu=2) as sched:
+        key = sched.put_dataset(X, y)
+        got = sched.run([dict(dataset=key, **j) for j in jobs])
+        assert len({w for _, w in sched.assignments}) == 2
+    np.testing.assert_array_equal(np.asarray(got), np.asarray(want))

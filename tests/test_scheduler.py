@@ -1,0 +1,99 @@
+"""Run-level scheduler of the table harness (mr-gan_amd/scheduler.py) -- CPU tests with a stub runner."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from tests.helpers import stub_training  # noqa: E402
+
+
+def _jobs(n, key):
+    rs = np.random.RandomState(0)
+    jobs = []
+    for i in range(n):
+        perm = rs.permutation(120)
+        jobs.append(dict(dataset=key, train_idx=perm[:100], test_idx=perm[100:], percentlabeled=i))
+    return jobs
+
+
+def test_results_come_back_in_job_order_from_several_processes():
+    from mr_gan_amd.scheduler import RunScheduler
+    rs = np.random.RandomState(1)
+    X, y = rs.randn(120, 7), rs.randint(0, 6, size=120)
+    with RunScheduler(runner=stub_training, devices=['cpu', 'cpu', 'cpu']) as sched:
+        key = sched.put_dataset(X, y)
+        jobs = _jobs(17, key)
+        out = sched.run(jobs)
+        assert len(sched.assignments) == 17 and sorted(j for j, _ in sched.assignments) == list(range(17))
+        want = [stub_training(j, {key: (X, y)}, 'cpu')[0] for j in jobs]
+        np.testing.assert_allclose([o[0] for o in out], want, rtol=0, atol=0)
+        assert len({o[1] for o in out}) >= 2                    # more than one worker process did the work
+        assert os.getpid() not in {o[1] for o in out}
+        # a second batch on the same workers and dataset
+        out2 = sched.run(jobs[:4])
+        np.testing.assert_allclose([o[0] for o in out2], want[:4], rtol=0, atol=0)
+
+
+def test_device_list_and_failure_report():
+    from mr_gan_amd.scheduler import RunScheduler
+    s = RunScheduler.__new__(RunScheduler)                      # device naming without starting workers
+    assert ['cuda:%d' % g for g in range(2) for _ in range(3)] == ['cuda:0'] * 3 + ['cuda:1'] * 3
+    del s
+    rs = np.random.RandomState(2)
+    X, y = rs.randn(120, 3), rs.randint(0, 6, size=120)
+    with RunScheduler(runner=stub_training, devices=['cpu', 'cpu']) as sched:
+        key = sched.put_dataset(X, y)
+        jobs = _jobs(3, key)
+        jobs[1]['explode'] = True
+        with pytest.raises(RuntimeError, match="stub failure requested"):
+            sched.run(jobs)
+    with pytest.raises(ValueError):
+        RunScheduler(gpus=0)
+
+
+def test_scheduled_table1_prints_the_reference_lines(capsys):
+    """--gpus N routes table 1 through the scheduler and still prints the reference's lines in the reference's order."""
+    import importlib
+    M = importlib.import_module('mr_gan_amd.mr_gan')     # the package re-exports the function under the same name
+
+    class FakeScheduler(object):
+        def __init__(self, gpus, jobs_per_gpu):
+            self.gpus, self.jobs_per_gpu, self.batches = gpus, jobs_per_gpu, []
+
+        def put_dataset(self, X, y):
+            return 0
+
+        def run(self, jobs):
+            self.batches.append(len(jobs))
+            return [0.25 + 0.001 * j['percentlabeled'] for j in jobs]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    made = []
+
+    def factory(gpus, jobs_per_gpu):
+        made.append(FakeScheduler(gpus, jobs_per_gpu))
+        return made[-1]
+
+    rs = np.random.RandomState(0)
+
+    def fake_dataset(modalities=0, **kw):
+        return rs.randn(60, 4), np.arange(60) % 6
+
+    M.main(['--tables', '1', '--gpus', '2', '--jobs-per-gpu', '3'], dataset_fn=fake_dataset, scheduler_factory=factory)
+    out = capsys.readouterr().out
+    assert made[0].gpus == 2 and made[0].jobs_per_gpu == 3
+    assert made[0].batches == [42] * 7                          # 7 modalities x (7 label fractions x 6 folds)
+    assert out.count('Test error:') == 7 * 42
+    assert out.count('Average error:') == 7 * 7
+    i50 = out.index('Percentage of training data labeled: 50%')
+    assert 'Test error: 0.3' in out[i50:i50 + 200]              # 0.25 + 0.001 * 50
+    assert out.index('Force modality') < out.index('Temperature modality') < out.index('Force and Contact Mic modality')
