@@ -475,10 +475,15 @@ int dense_dx(mrgan_handle* h, const Dense& L, const void* dy, int rows, int nb, 
 // range that is cut into L.splits slabs, so the Adam kernel sums at most MAX_SLABS slabs per tensor.
 double dw_args(mrgan_handle* h, GemmArgs& g, const Dense& L, const void* x, const void* dy, int rows, int nseg) {
     memset(&g, 0, sizeof g);
-    const int vrows = (nseg - 1) * h->S + rows;
+    // bf16: reduce over ALL S rows of every segment.  The rows >= `rows` of dY are never written by any kernel (they keep
+    // the zeros of mrgan_create) and those of X are finite, so they add exact zeros -- and the reduction range becomes
+    // dense, which is what the LDS-DMA weight-gradient kernel and the grouped launch need (a ragged batch such as the
+    // reference's 50 otherwise fell back to one register-staged launch per product).
+    const bool dense = h->bf16 != 0;
+    const int vrows = dense ? nseg * h->S : (nseg - 1) * h->S + rows;
     g.M = L.Kp; g.N = L.Np; g.K = vrows; g.nbatch = 1; g.splits = L.splits; g.tiles_m = ceil_div(L.Kp, 128);
     g.kchunk = (int)round_up(ceil_div(vrows, L.splits), 64);
-    g.seg_stride = h->S; g.seg_rows = rows;
+    g.seg_stride = h->S; g.seg_rows = dense ? h->S : rows;
     g.A = x; g.a_si = 1; g.a_sk = L.Kp;
     g.B = dy; g.b_sk = L.Np; g.b_sj = 1;
     g.e = base_epi(h);

@@ -197,7 +197,8 @@ def test_bf16_steps_track_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize("D,B", [(400, 256),      # reference-sized input, several row tiles
+@pytest.mark.parametrize("D,B", [(400, 50),       # the reference's ragged batch: the weight gradients reduce over the padding rows too
+                                 (400, 256),      # reference-sized input, several row tiles
                                  (3632, 512),     # all three modalities fused, one rank's shard of batch 4096
                                  (2432, 1024),    # config 4: contact-mic log-mel only
                                  (512, 4096)])    # config 2: the bench workload at full size
@@ -208,6 +209,10 @@ def test_bf16_gradients_track_oracle(D, B):
     _, gd, _ = orc.disc_grads(**case.disc_inputs(0, 0))
     eng = _engine(D, B, 1, flags=E.FLAG_FLAT_GRADS)
     _load(eng, case)
+    # an evaluation first: it fills ALL rows of the activation buffers (also the padding rows of a ragged batch),
+    # which the training step afterwards must tolerate
+    rs = np.random.RandomState(5)
+    eng.eval_error(_t(rs.randn(3 * 128 + 7, D).astype(np.float32)), _t(rs.randint(0, 6, size=3 * 128 + 7), torch.int32))
     da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]), _t(case.z1[0]))
     eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
     # bf16 operands through up to ten chained contractions: the gradient direction must be preserved
