@@ -77,37 +77,24 @@ __device__ __forceinline__ void wait_groups(int n) {
 // PIPE: the fragments of k-tile kt+1 are read from LDS into a second register set while the MFMAs of k-tile kt run
 // (needs k-tile kt+1 landed one iteration early, so NS >= 4 to keep two k-tiles of LDS-DMA in flight).  Meant for
 // launches with <= 1 block per CU, where no second block hides the barrier -> ds_read -> MFMA latency chain.
+// one output tile (batch, tile_m, tile_n) of the product described by g: prologue, main loop, epilogue, ending with
+// the barrier after which the LDS ring may be refilled
 template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR, bool PIPE = false>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmArgs g) {
+__device__ __forceinline__ void kc_tile(const GemmArgs& g, const int batch, const int tile_m, const int tile_n, char* lds) {
     constexpr int NW = WM * WN;
     constexpr int MR = BM / WM / 32, NR = BNT / WN / 32;   // 32x32 accumulators per wave
     constexpr int A_BYTES = BM * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BNT / 8 / NW;   // wave-instructions per wave per k-tile (8 rows each)
     static_assert(NS >= 2 && NS <= 4 && (!PIPE || NS >= 3), "ring depth");
     static_assert(MR >= 1 && NR >= 1 && A_INSTR >= 1 && B_INSTR >= 1 && BM % (8 * NW) == 0 && BNT % (8 * NW) == 0, "tile/wave layout");
-    extern __shared__ __attribute__((aligned(16))) char lds[];        // max(NS * STAGE, BM * BNT * 2 + scratch) bytes
-
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int ntn = (g.N + BNT - 1) / BNT, ntm = (g.M + BM - 1) / BM;
-    const int ntiles = ntn * ntm * g.nbatch;
     const int lrow = lane >> 3, lp = lane & 7;       // lane -> (row within an instruction's 8 rows, 16-B chunk)
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = (g.e.ablate & 4) ? 0 : g.K / BK;
-
-    // Persistent block: walks the tiles bid, bid + grid, ...  One tile's output stores drain while the next tile's
-    // loads and MFMAs run, and co-resident blocks drift out of phase instead of all hitting HBM at once.
-#ifdef MRGAN_STAMPS
-    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
-#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_prev; st_prev = n_; } while (0)
-#else
 #define STAMP(i)
-#endif
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        const int tidx = xcd_tile(tl, ntiles);
-        const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
-        const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
+    {
         const int row_blk = tile_m * BM, col_blk = tile_n * BNT;
 
         // descriptors bounded at the operand's end: rows >= M (A) / >= N (Bt) read as zeros
@@ -277,10 +264,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
         __syncthreads();        // the copy-out has read the staged tile: the ring may be refilled
         STAMP(5);
     }
-#ifdef MRGAN_STAMPS
-    if (g.e.slab && threadIdx.x == 0)
-        for (int i = 0; i < 6; ++i) ((unsigned long long*)g.e.slab)[(long)blockIdx.x * 8 + i] = st_[i];
-#endif
+#undef STAMP
+}
+
+// Persistent block: walks the tiles bid, bid + grid, ...  One tile's output stores drain while the next tile's
+// loads and MFMAs run, and co-resident blocks drift out of phase instead of all hitting HBM at once.
+template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR, bool PIPE = false>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];        // max(NS * STAGE, BM * BNT * 2 + scratch) bytes
+    const int ntn = (g.N + BNT - 1) / BNT, ntm = (g.M + BM - 1) / BM;
+    const int ntiles = ntn * ntm * g.nbatch;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tidx = xcd_tile(tl, ntiles);
+        const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
+        const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
+        kc_tile<EPI, BM, BNT, WM, WN, NS, VAR, PIPE>(g, batch, tile_m, tile_n, lds);
+    }
 }
 
 thread_local const char* g_last_kernel = "";
