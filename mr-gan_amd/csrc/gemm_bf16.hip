@@ -80,7 +80,15 @@ __device__ __forceinline__ void wait_groups(int n) {
 // one output tile (batch, tile_m, tile_n) of the product described by g: prologue, main loop, epilogue, ending with
 // the barrier after which the LDS ring may be refilled
 template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR, bool PIPE = false>
-__device__ __forceinline__ void kc_tile(const GemmArgs& g, const int batch, const int tile_m, const int tile_n, char* lds) {
+#ifdef MRGAN_STAMPS
+struct KcStamps { unsigned long long acc[6], prev; };      // make STAMPS=1: cycles per phase, summed over the block's tiles
+#define KC_STAMPS_PARAM , KcStamps& stamps_
+#define KC_STAMPS_ARG , stamps_
+#else
+#define KC_STAMPS_PARAM
+#define KC_STAMPS_ARG
+#endif
+__device__ __forceinline__ void kc_tile(const GemmArgs& g, const int batch, const int tile_m, const int tile_n, char* lds KC_STAMPS_PARAM) {
     constexpr int NW = WM * WN;
     constexpr int MR = BM / WM / 32, NR = BNT / WN / 32;   // 32x32 accumulators per wave
     constexpr int A_BYTES = BM * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
@@ -93,7 +101,11 @@ __device__ __forceinline__ void kc_tile(const GemmArgs& g, const int batch, cons
     const int lrow = lane >> 3, lp = lane & 7;       // lane -> (row within an instruction's 8 rows, 16-B chunk)
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = (g.e.ablate & 4) ? 0 : g.K / BK;
+#ifdef MRGAN_STAMPS
+#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); stamps_.acc[i] += n_ - stamps_.prev; stamps_.prev = n_; } while (0)
+#else
 #define STAMP(i)
+#endif
     {
         const int row_blk = tile_m * BM, col_blk = tile_n * BNT;
 
@@ -274,12 +286,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
     extern __shared__ __attribute__((aligned(16))) char lds[];        // max(NS * STAGE, BM * BNT * 2 + scratch) bytes
     const int ntn = (g.N + BNT - 1) / BNT, ntm = (g.M + BM - 1) / BM;
     const int ntiles = ntn * ntm * g.nbatch;
+#ifdef MRGAN_STAMPS
+    KcStamps stamps_ = {{0, 0, 0, 0, 0, 0}, __builtin_amdgcn_s_memtime()};
+#endif
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int tidx = xcd_tile(tl, ntiles);
         const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
         const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
-        kc_tile<EPI, BM, BNT, WM, WN, NS, VAR, PIPE>(g, batch, tile_m, tile_n, lds);
+        kc_tile<EPI, BM, BNT, WM, WN, NS, VAR, PIPE>(g, batch, tile_m, tile_n, lds KC_STAMPS_ARG);
     }
+#ifdef MRGAN_STAMPS
+    if (g.e.slab && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) ((unsigned long long*)g.e.slab)[(long)blockIdx.x * 8 + i] = stamps_.acc[i];
+#endif
 }
 
 thread_local const char* g_last_kernel = "";
