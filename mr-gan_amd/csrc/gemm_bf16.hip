@@ -77,9 +77,6 @@ __device__ __forceinline__ void wait_groups(int n) {
 // PIPE: the fragments of k-tile kt+1 are read from LDS into a second register set while the MFMAs of k-tile kt run
 // (needs k-tile kt+1 landed one iteration early, so NS >= 4 to keep two k-tiles of LDS-DMA in flight).  Meant for
 // launches with <= 1 block per CU, where no second block hides the barrier -> ds_read -> MFMA latency chain.
-// one output tile (batch, tile_m, tile_n) of the product described by g: prologue, main loop, epilogue, ending with
-// the barrier after which the LDS ring may be refilled
-template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR, bool PIPE = false>
 #ifdef MRGAN_STAMPS
 struct KcStamps { unsigned long long acc[6], prev; };      // make STAMPS=1: cycles per phase, summed over the block's tiles
 #define KC_STAMPS_PARAM , KcStamps& stamps_
@@ -88,6 +85,9 @@ struct KcStamps { unsigned long long acc[6], prev; };      // make STAMPS=1: cyc
 #define KC_STAMPS_PARAM
 #define KC_STAMPS_ARG
 #endif
+// one output tile (batch, tile_m, tile_n) of the product described by g: prologue, main loop, epilogue, ending with
+// the barrier after which the LDS ring may be refilled
+template <int EPI, int BM, int BNT, int WM, int WN, int NS, int VAR, bool PIPE = false>
 __device__ __forceinline__ void kc_tile(const GemmArgs& g, const int batch, const int tile_m, const int tile_n, char* lds KC_STAMPS_PARAM) {
     constexpr int NW = WM * WN;
     constexpr int MR = BM / WM / 32, NR = BNT / WN / 32;   // 32x32 accumulators per wave
