@@ -495,7 +495,7 @@ struct DwJob { const Dense* L; const void* x; const void* dy; };
 
 // the weight-gradient products of one sub-step: one grouped launch when the bf16 fast path takes them all,
 // one launch per product otherwise
-int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, hipStream_t s) {
+int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, hipStream_t s, const FoldJob* fold = nullptr) {
     GemmArgs gs[KS_GROUP_MAX];
     double fl[KS_GROUP_MAX], total = 0.0;
     if (n > KS_GROUP_MAX) return fail(-1, "dense_dw_all: too many products");
@@ -503,12 +503,13 @@ int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, 
     if (h->bf16) {
         const char* kname = "gemm";
         prof_arm(h);
-        const int r = launch_gemm_bf16_dw_group(gs, n, s, &kname);
+        const int r = launch_gemm_bf16_dw_group(gs, n, s, &kname, fold);
         prof_done(h, kname, total);
         if (r < 0) return fail(r, "grouped weight-gradient launch failed");
         if (r == 0) return 0;
     }
     for (int i = 0; i < n; ++i) CHK(run_gemm(h, EPI_SLAB, gs[i], fl[i], s));
+    if (fold) PROF("reduce_partials_kernel", launch_reduce_partials(fold->src, fold->nsrc, fold->stride, fold->n, fold->ngroups, fold->dst, s));
     return 0;
 }
 
@@ -648,15 +649,15 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         hd.part = h->head_part; hd.part_stride = h->head_stride; hd.off_db = h->Fp * KMAX; hd.off_dbf = h->Fp * KMAX + KMAX;
         hd.loss_part = h->loss_part;
         PROF("head_kernel", launch_head(h->bf16, hd, s));
-        PROF("reduce_partials_kernel", launch_reduce_partials(h->head_part, h->nblk_head, h->head_stride, h->head_stride, h->head_groups,
-                                                     h->head_red, s));
         for (int l = 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 3, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_SUM, h->cs_db[l - 1], nullptr, s));
         {
             DwJob jobs[5];
             for (int l = 0; l < 5; ++l) jobs[l] = DwJob{&h->d[l], h->xin[l], h->dpre[l]};
-            CHK(dense_dw_all(h, jobs, 5, B, 3, s));
+            // the loss head's per-block weight-gradient partials are folded by extra blocks of the same launch
+            const FoldJob fold = {h->head_part, h->head_red, (long)h->head_stride, h->nblk_head, h->head_stride, h->head_groups, 0};
+            CHK(dense_dw_all(h, jobs, 5, B, 3, s, &fold));
         }
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_D, ADAM_REDUCE_ONLY, true, s));
     } else if (phase == MRGAN_D_ADAM) {

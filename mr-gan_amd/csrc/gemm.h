@@ -313,9 +313,13 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
 
 // up to KS_GROUP_MAX weight-gradient products launched as one grid (gemm_bf16.hip)
 constexpr int KS_GROUP_MAX = 6;
+// a fold of per-block partial rows that rides along in the grouped launch (the loss head's weight-gradient partials):
+// dst[grp][i] = sum of src[p][i] over p = grp, grp + ngroups, ...   ; blocks_x * ngroups extra blocks of 256 threads
+struct FoldJob { const float* src; float* dst; long stride; int nsrc, n, ngroups, blocks_x; };
 struct KsGroup {
     int n;
     int blk_end[KS_GROUP_MAX];       // exclusive prefix sums of the problems' block counts
+    FoldJob fold;                    // fold.blocks_x == 0: none
     GemmArgs g[KS_GROUP_MAX];
 };
 
@@ -323,6 +327,7 @@ struct KsGroup {
 // kname (optional) receives the name of the kernel instantiation that was launched, spelled as rocprofv3 prints it
 int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
 int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
-int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname = nullptr);   // 1 = not applicable
+int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname = nullptr,
+                              const FoldJob* fold = nullptr);   // 1 = not applicable
 
 }  // namespace mrgan

@@ -446,6 +446,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_fast_kernel(const G
 // still share an XCD (a constant rotation of b % 8), which is all the XCD-aware tile order of ks_fast_body relies on.
 template <int NS, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_ks_group_kernel(const KsGroup grp) {
+    const int ngemm = grp.blk_end[grp.n - 1];
+    if ((int)blockIdx.x >= ngemm) {
+        // the fold job's blocks (see FoldJob): only the first 256 threads of a block take part
+        const FoldJob& f = grp.fold;
+        const int fb = (int)blockIdx.x - ngemm, gidx = fb / f.blocks_x;
+        const int i = (fb - gidx * f.blocks_x) * 256 + (int)threadIdx.x;
+        if (threadIdx.x >= 256 || i >= f.n) return;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = gidx;
+        for (; p + 3 * f.ngroups < f.nsrc; p += 4 * f.ngroups) {
+            s0 += f.src[(long)p * f.stride + i]; s1 += f.src[(long)(p + f.ngroups) * f.stride + i];
+            s2 += f.src[(long)(p + 2 * f.ngroups) * f.stride + i]; s3 += f.src[(long)(p + 3 * f.ngroups) * f.stride + i];
+        }
+        for (; p < f.nsrc; p += f.ngroups) s0 += f.src[(long)p * f.stride + i];
+        f.dst[(long)gidx * f.stride + i] = (s0 + s1) + (s2 + s3);
+        return;
+    }
     int i = 0, b0 = 0;
 #pragma unroll
     for (int j = 0; j < KS_GROUP_MAX - 1; ++j)
@@ -641,7 +658,7 @@ static bool ks_dense_k(const GemmArgs& g) {
 }
 
 // n weight-gradient products as one launch; returns 1 (nothing launched) when a problem does not fit the grouped kernel
-int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname) {
+int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname, const FoldJob* fold) {
     if (n < 1 || n > KS_GROUP_MAX) return 1;
     static const int enabled = env_int("MRGAN_KS_GROUP", 1);
     if (!enabled) return 1;
@@ -655,6 +672,11 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
         total += blocks;
         grp.blk_end[i] = total;
         grp.g[i] = gs[i];
+    }
+    if (fold && fold->n > 0) {
+        grp.fold = *fold;
+        grp.fold.blocks_x = ceil_div(fold->n, 256);
+        total += grp.fold.blocks_x * fold->ngroups;
     }
     // The loop is bound by the LDS: ds_read_b64_tr_b16 moves 512 B per wave-instruction, and 128x128 blocks of 8 waves
     // (64x32 per wave) need 1.5 of them per MFMA.  Four waves of 64x64 need 1.0, and with a 2-stage ring (64 KiB) two
