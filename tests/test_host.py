@@ -161,3 +161,22 @@ def test_engine_refuses_to_run_without_gpu():
     from mr_gan_amd import engine as E
     with pytest.raises(RuntimeError):
         E.Engine(E.default_config(16, 50))
+
+
+def test_bench_algorithmic_flops_match_survey():
+    """SURVEY.md 8(d): D-step 2B[P_G + 3P_D + 3P_D + 3(P_D - 1000D)], G-step 2B[P_G + 2P_mid + P_mid + P_G + (P_G - 50000)];
+    85.13 + 44.27 = 129.40 GFLOP per step at B = 4096, D = 512 -- the figure bench.py's roofline.step uses."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, D = 4096, 512
+    fl = bench.algorithmic_flops(B, D)
+    PD = 1000 * D + 751500
+    Pmid = PD - 1500
+    PG = 300000 + 500 * D
+    d_step = 2.0 * B * (PG + 3 * PD + 3 * PD + 3 * (PD - 1000 * D))
+    g_step = 2.0 * B * (PG + 2 * Pmid + Pmid + PG + (PG - 50000))
+    assert abs(fl["total"] - (d_step + g_step)) < 1e-6 * fl["total"]
+    assert abs(fl["total"] / 1e9 - 129.40) < 0.01
+    assert abs(d_step / 1e9 - 85.13) < 0.01 and abs(g_step / 1e9 - 44.27) < 0.01
