@@ -149,6 +149,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)(batch * e.seg_step),
                                     (pf ? pf->iter : (e.st ? e.st->iter : 0u)) + (uint32_t)batch * e.iter_step);
 
+        // activated values for the column-sum pass below: ordinary registers, so a launch without column sums never
+        // moves them back into the accumulator file
+        float keep[MR][NR][16];
 #pragma unroll
         for (int ni = 0; ni < NR; ++ni) {
             const int col = col_blk + (wn * NR + ni) * 32 + lc;
@@ -204,7 +207,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             }
                             o = v;
                         }
-                        acc[mi][ni][r] = v;                                  // kept for the column-sum pass
+                        keep[mi][ni][r] = v;
                         if constexpr (STAGED) tile[(row - row_blk) * bn + (col - col_blk)] = Elem<T>::from_f32(o);
                         else if (row < M && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(o);
                     }
@@ -248,7 +251,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             for (int r = 0; r < 16; ++r) {
                                 const int row = rsub + (r & 3) + 8 * (r >> 2);
                                 const bool ok = row < M;
-                                const float v = ok ? acc[mi][ni][r] : 0.f;
+                                const float v = ok ? keep[mi][ni][r] : 0.f;
                                 float hv;
                                 if constexpr (STAGED) hv = (ok && cok) ? Elem<T>::to_f32(htile[(row - row_blk) * bn + (col - col_blk)]) : mu;
                                 else hv = (ok && cok) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : mu;
@@ -257,7 +260,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                         } else {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const float v = (rsub + (r & 3) + 8 * (r >> 2) < M) ? acc[mi][ni][r] : 0.f;
+                                const float v = (rsub + (r & 3) + 8 * (r >> 2) < M) ? keep[mi][ni][r] : 0.f;
                                 s1 += v; s2 = fmaf(v, v, s2);
                             }
                         }
