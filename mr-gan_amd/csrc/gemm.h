@@ -179,11 +179,12 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                     if constexpr (EPI == EPI_FWD) {
                         if (noisy) normal4(nkey, (e.row0 + (uint32_t)r4) >> 2, (uint32_t)col, nz);
                     }
+                    float o4[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * q + j, row = r4 + j;
                         float v = acc[mi][ni][r];
-                        float o;
+                        float& o = o4[j];
                         if constexpr (EPI == EPI_FWD) {
                             v += bias;
                             if (act == ACT_RELU) {
@@ -208,8 +209,21 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             o = v;
                         }
                         keep[mi][ni][r] = v;
-                        if constexpr (STAGED) tile[(row - row_blk) * bn + (col - col_blk)] = Elem<T>::from_f32(o);
-                        else if (row < M && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(o);
+                        if constexpr (!STAGED) { if (row < M && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(o); }
+                    }
+                    if constexpr (STAGED) {
+                        // rows r4 .. r4+3 of one column: convert in pairs (one v_cvt_pk per two values), store the halves
+                        T* tp = tile + (r4 - row_blk) * bn + (col - col_blk);
+                        if constexpr (sizeof(T) == 2) {
+                            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+                            typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+                            const bf16x2_t p01 = __builtin_convertvector((f32x2_t){o4[0], o4[1]}, bf16x2_t);
+                            const bf16x2_t p23 = __builtin_convertvector((f32x2_t){o4[2], o4[3]}, bf16x2_t);
+                            tp[0] = p01[0]; tp[bn] = p01[1]; tp[2 * bn] = p23[0]; tp[3 * bn] = p23[1];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) tp[j * bn] = Elem<T>::from_f32(o4[j]);
+                        }
                     }
                 }
                 if constexpr (EPI == EPI_FWD) {
