@@ -1,7 +1,12 @@
-"""Import shim: the product package lives in the directory `mr-gan_amd/` (a name Python cannot import
-directly), so `import mr_gan_amd` resolves its submodules there."""
-import os as _os
+"""mr_gan_amd -- MI355X-native feature-matching semi-supervised GAN training path of
+Healthcare-Robotics/mr-gan (mr_gan.py), behind the reference's own entry points.
 
-__path__ = [_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "mr-gan_amd")]
-with open(_os.path.join(__path__[0], "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(__path__[0], "__init__.py"), "exec"))
+    from mr_gan_amd import mr_gan, dataset, MRGAN
+"""
+from mr_gan_amd.data import (select_labeled, standard_scale, synthetic_blobs, synthetic_mreo,  # noqa: F401
+                             tiled_permutation)
+from mr_gan_amd.model import MRGAN  # noqa: F401
+from mr_gan_amd.mr_gan import dataset, mr_gan  # noqa: F401
+
+__all__ = ["mr_gan", "dataset", "MRGAN", "synthetic_mreo", "synthetic_blobs", "standard_scale", "select_labeled",
+           "tiled_permutation"]

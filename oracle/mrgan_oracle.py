@@ -3,7 +3,7 @@
 This file is a plain-numpy restatement of the arithmetic that the reference builds
 through Keras 2.0.9 / Theano 0.9.0 in /root/reference/mr_gan.py:109-171 and drives from
 the loop at mr_gan.py:183-230.  Only tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg may import it; the product path (mr-gan_amd/) never does.
+cpu_baseline leg may import it; the product path (mr_gan_amd/) never does.
 
 PARITY UNPINNED: the reference ships no tests, golden vectors, saved weights or data, and
 cannot be parsed or imported in this container (Python-2 source, Keras/Theano absent; see
@@ -333,7 +333,7 @@ def tiled_permutation(rng_perm, n_pool, n_total):
 
 
 # ----------------------------------------------------------------------------------------
-# The build's device noise generator, restated (mr-gan_amd/csrc/common.h: mix32 / noise_key / normal4):
+# The build's device noise generator, restated (mr_gan_amd/csrc/common.h: mix32 / noise_key / normal4):
 # a counter hash keyed by (seed, site*256+segment, sub-step); per (row>>2, column) it yields the four
 # normals of rows 4q..4q+3 at that column through two Box-Muller pairs on 16-bit uniforms.
 # ----------------------------------------------------------------------------------------

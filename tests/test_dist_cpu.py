@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the data-parallel protocol (mr-gan_amd/dist.py) on CPU.
+"""world_size-2 gloo test of the data-parallel protocol (mr_gan_amd/dist.py) on CPU.
 
 The HIP engine cannot run here, so each rank drives dist.DataParallel through a stand-in PhaseBackend whose
 phases are the CPU oracle cut at the same points as include/mrgan_abi.h (MRGAN_D_* / MRGAN_G_* phases) and whose

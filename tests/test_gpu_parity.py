@@ -383,7 +383,7 @@ def _dp_worker(rank, world, port, exact, q):
 
 @pytest.mark.parametrize("exact", [True, False])
 def test_two_process_data_parallel_on_one_gpu(exact):
-    """mr-gan_amd/dist.py end to end with two OS processes sharing the GPU: replicas end bit-identical; with the
+    """mr_gan_amd/dist.py end to end with two OS processes sharing the GPU: replicas end bit-identical; with the
     statistic exchanges (exact) they also reproduce the single-process full-batch step."""
     import socket
     import torch.multiprocessing as mp

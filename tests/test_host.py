@@ -146,7 +146,7 @@ def test_default_config_and_workspace_size_without_gpu():
 
 def test_product_path_never_imports_oracle():
     """Only tests/, smoke() and bench.py's cpu_baseline leg may use oracle/ (mentions in comments are fine)."""
-    pkg = os.path.join(ROOT, "mr-gan_amd")
+    pkg = os.path.join(ROOT, "mr_gan_amd")
     pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|#\s*include\s*[\"<][^\">]*oracle)|import_module\(['\"]oracle|dlopen\([^)]*oracle", re.M)
     for dirpath, _, files in os.walk(pkg):
         for f in files:

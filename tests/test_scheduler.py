@@ -1,4 +1,4 @@
-"""Run-level scheduler of the table harness (mr-gan_amd/scheduler.py) -- CPU tests with a stub runner."""
+"""Run-level scheduler of the table harness (mr_gan_amd/scheduler.py) -- CPU tests with a stub runner."""
 import os
 import sys
 
