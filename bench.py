@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--d", type=int, default=512)
     ap.add_argument("--rows", type=int, default=65536)
+    ap.add_argument("--hidden", type=int, default=0,
+                    help="0 = the reference's layer widths (mr_gan.py:111-128); W = BASELINE configs[4]'s wide stack: five "
+                         "discriminator layers and two generator layers of width W")
     ap.add_argument("--labeled-per-class", type=int, default=100)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,6 +143,12 @@ def main():
     X, y, xl, yl = build_problem(args, rank)
     B, D = args.batch, args.d
     cfg = E.default_config(D, B)
+    g_hidden, d_hidden = (500, 500), (1000, 500, 250, 250, 250)
+    if args.hidden:
+        g_hidden, d_hidden = (args.hidden,) * 2, (args.hidden,) * 5
+        cfg.g_hidden[0], cfg.g_hidden[1] = g_hidden
+        for i, w in enumerate(d_hidden):
+            cfg.d_hidden[i] = w
     cfg.dtype = E.BF16 if args.dtype == "bf16" else E.F32
     cfg.seed = 1
     cfg.rank, cfg.world = rank, world
@@ -188,6 +197,7 @@ def main():
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize(dev)
+        eng.read_metrics(reset=True)          # train_metrics below cover the timed steps only
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -220,7 +230,7 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
-    fl = algorithmic_flops(B, D)
+    fl = algorithmic_flops(B, D, g_hidden, d_hidden)
     peak = PEAK_TFLOPS[args.dtype]
     # dominant kernel = the GEMM kernel instantiation with the largest share of device time in the profiled pass;
     # its algorithmic FLOPs per launch come from the library (2 x logical M*N*K of each dense-layer product)
@@ -262,8 +272,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: synthetic N=%d x D=%d, K=6, batch %d per GPU, labeled %d/class; one step = "
-                               "D sub-step (3B rows) + G sub-step (2B rows) + both Adam updates" % (args.rows, D, B, args.labeled_per_class),
+        "config": {"workload": "%s: synthetic N=%d x D=%d, K=6, batch %d per GPU, labeled %d/class; one step = "
+                               "D sub-step (3B rows) + G sub-step (2B rows) + both Adam updates"
+                               % ("BASELINE configs[4] geometry (hidden %d x 5, generator %d x 2) on one GPU" % (args.hidden, args.hidden)
+                                  if args.hidden else "BASELINE configs[1]", args.rows, D, B, args.labeled_per_class),
                    "global_batch": B * world, "parallelism": "dp%d" % world if world > 1 else "single",
                    "batch_statistics": ("local_stats (per shard)" if args.local_stats else "synced over ranks") if world > 1 else "n/a",
                    "launch": "eager phases + RCCL all-reduce" if world > 1 else ("eager" if args.no_graph else "hipGraph replay")},
@@ -271,7 +283,7 @@ def main():
         "train_metrics": {"mean_loss_lab": metrics[0] / args.steps, "mean_loss_unl": metrics[1] / args.steps,
                           "mean_train_err": metrics[2] / args.steps, "mean_loss_gen": metrics[3] / args.steps},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.hidden:
         out["cpu_baseline"] = cpu_baseline(args, X, xl, yl)
     print(json.dumps(out))
     sys.stdout.flush()

@@ -6,6 +6,7 @@ namespace mrgan {
 
 constexpr int KMAX = 8;            // classes are padded to 8 logits (reference: 6 materials, mr_gan.py:80)
 constexpr int HEAD_ROWS = 32;      // rows per loss-head block
+constexpr int HEAD_CHUNK = 256;    // feature columns of the loss head held in LDS at a time (wider layers are walked in chunks)
 
 // ---- staging: rows of the (scaled) data matrix -> noisy discriminator input; z -> generator input ----
 struct StageSeg {

@@ -36,10 +36,13 @@ template <> __device__ __forceinline__ void store8<__bf16>(__bf16* p, const floa
 // stage: gather rows (optionally by index) of the resident fp32 matrix, add GaussianNoise(sigma)
 // (mr_gan.py:118), convert to T, zero the padding columns.  Also draws z when asked to, and --
 // being the first kernel of every sub-step -- publishes the next DevState slot.
-// thread <-> (4 rows x 4 columns): four hash calls give the 16 normals; loads are 16 B per row.
+// wave <-> 32 rows x 128 columns.  The noise generator (common.h) delivers a 32x32 block in the MFMA accumulator
+// layout (lane = column, 16 rows in registers); the integer sums (|s| <= 4064) go through a per-wave int16 LDS image so
+// that global loads and stores move 8 consecutive columns per lane (2 x 16 B in, 16 B out).
 // =========================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
+    __shared__ __attribute__((aligned(16))) short nlds[4][32][128 + 8];          // +8: rows 272 B apart (bank spread for the 2-byte writes)
     const DevState st = *a.cur;
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && a.next) {
         DevState nx;
@@ -51,50 +54,52 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
         *a.next = nx;
     }
     const StageSeg& sg = a.s[blockIdx.z];
-    const int c0 = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
-    const int r4 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
-    if (c0 >= sg.cols_pad || r4 >= sg.rows) return;
+    const int lane = threadIdx.x & 63, lc = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rbase = (blockIdx.y * 4 + wave) * 32, cbase = (int)blockIdx.x * 128;
+    if (rbase >= sg.rows || cbase >= sg.cols_pad) return;          // wave-uniform; no block-level barrier below
     const long o = sg.stream ? (long)st.batch * sg.rows : 0;
     T* out = (T*)sg.out;
-    float nz[4][4];                         // [col][row]
+    const bool noisy = sg.gen || sg.sigma > 0.f;
+    if (noisy) {
+        const uint32_t rowhash = noise_rowhash(noise_key(a.seed, sg.site * 256u + sg.seg, st.iter + sg.iter_off), a.row0 + (uint32_t)(rbase + lc));
+        const i32x4 hfrag = hadamard_frag(lane);
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int cb = 0; cb < 4; ++cb) {
+            const int c0 = cbase + cb * 32;
+            if (c0 >= sg.cols) break;                              // wave-uniform; columns beyond are never read back
+            const i32x16 nz = noise_block(rowhash, (uint32_t)c0 >> 5, lane, hfrag);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nz[c][j] = 0.f;
-    if (sg.gen || sg.sigma > 0.f) {
-        const uint32_t nkey = noise_key(a.seed, sg.site * 256u + sg.seg, st.iter + sg.iter_off);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c0 + c < sg.cols) normal4(nkey, (a.row0 + (uint32_t)r4) >> 2, (uint32_t)(c0 + c), nz[c]);
+            for (int r = 0; r < 16; ++r) nlds[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][cb * 32 + lc] = (short)nz[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // same wave, in-order LDS: the reads below see the writes
     }
-    const bool vec_ok = !sg.gen && (sg.ld & 3) == 0 && ((uintptr_t)sg.src & 15) == 0 && c0 + 3 < sg.cols;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = r4 + j;
+    const float sigs = (sg.gen ? 1.0f : sg.sigma) * NOISE_SCALE;
+    const int cg = (lane & 15) * 8, rl = lane >> 4;                // lane <-> (8 columns, every 4th row)
+    const int col = cbase + cg;
+    if (col >= sg.cols_pad) return;
+    const bool vec_ok = !sg.gen && (sg.ld & 3) == 0 && ((uintptr_t)sg.src & 15) == 0 && col + 7 < sg.cols;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int rr = it * 4 + rl, row = rbase + rr;
         if (row >= sg.rows) break;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (!sg.gen) {
             const long sr = sg.idx ? (long)sg.idx[o + row] : (o + row);
-            const float* src = sg.src + sr * sg.ld + c0;
-            if (vec_ok) { const f32x4 x = *(const f32x4*)src; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; }
+            const float* src = sg.src + sr * sg.ld + col;
+            if (vec_ok) load8<float>(src, v);
             else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (c0 + c < sg.cols) v[c] = src[c];
+                for (int c = 0; c < 8; ++c) if (col + c < sg.cols) v[c] = src[c];
             }
         }
+        if (noisy && col < sg.cols) {
+            const s16x8 nz = *(const s16x8*)&nlds[wave][rr][cg];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c0 + c < sg.cols) v[c] = sg.gen ? nz[c][j] : v[c] + sg.sigma * nz[c][j];
-            else v[c] = 0.f;
+            for (int c = 0; c < 8; ++c) if (col + c < sg.cols) v[c] = fmaf(sigs, (float)nz[c], v[c]);
         }
-        T* dst = out + (long)row * sg.ldo + c0;
-        if constexpr (sizeof(T) == 2) {
-            bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            *(bf16x4*)dst = w;
-        } else {
-            f32x4 w = {v[0], v[1], v[2], v[3]};
-            *(f32x4*)dst = w;
-        }
+        store8<T>(out + (long)row * sg.ldo + col, v);
     }
 }
 
@@ -226,10 +231,12 @@ constexpr int HR = HEAD_ROWS;
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float hl[];
-    const int LDF = a.feat + 8;
-    float* f_lds = hl;                         // [HR][LDF]
-    float* w_lds = f_lds + HR * LDF;           // [feat][KMAX]
-    float* dl_lds = w_lds + a.feat * KMAX;     // [HR][KMAX]
+    // the feature dimension is walked in chunks of CH <= 256 columns (one chunk for the reference's 250-wide layer)
+    const int CH = min(a.feat, HEAD_CHUNK), nch = (a.feat + CH - 1) / CH;     // a ragged last chunk is zero-filled
+    const int LDF = CH + 8;
+    float* f_lds = hl;                         // [HR][LDF]   current chunk of f
+    float* w_lds = f_lds + HR * LDF;           // [CH][KMAX]  matching rows of W6
+    float* dl_lds = w_lds + CH * KMAX;         // [HR][KMAX]
     float* red = dl_lds + HR * KMAX;           // [4 waves][4]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -238,22 +245,23 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     const int blk = seg * gridDim.x + blockIdx.x;
     const T* f = (const T*)a.f + (long)seg * a.f_bs;
 
-    const int cpr = a.feat / 8;                // 8-element chunks per row
-    for (int ci = t; ci < HR * cpr; ci += 256) {
-        const int r = ci / cpr, c = (ci - r * cpr) * 8;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (row_blk + r < a.rows) load8<T>(f + (long)(row_blk + r) * a.ldf + c, v);
-        *(f32x4*)(f_lds + r * LDF + c) = (f32x4){v[0], v[1], v[2], v[3]};
-        *(f32x4*)(f_lds + r * LDF + c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-    }
-    for (int k = t; k < a.feat; k += 256) {
-        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
-        if (k < a.feat_valid) { w0 = *(const f32x4*)(a.w + (long)k * a.ldw); w1 = *(const f32x4*)(a.w + (long)k * a.ldw + 4); }
+    const int cpr = CH / 8;                    // 8-element chunks per row
+    auto load_chunk = [&](int c0) {
+        for (int ci = t; ci < HR * cpr; ci += 256) {
+            const int r = ci / cpr, c = (ci - r * cpr) * 8;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (row_blk + r < a.rows && c0 + c < a.feat) load8<T>(f + (long)(row_blk + r) * a.ldf + c0 + c, v);
+            *(f32x4*)(f_lds + r * LDF + c) = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(f_lds + r * LDF + c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
+        for (int k = t; k < CH; k += 256) {
+            f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+            if (c0 + k < a.feat_valid) { w0 = *(const f32x4*)(a.w + (long)(c0 + k) * a.ldw); w1 = *(const f32x4*)(a.w + (long)(c0 + k) * a.ldw + 4); }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { if (c >= a.classes) w0[c] = 0.f; if (c + 4 >= a.classes) w1[c] = 0.f; }
-        *(f32x4*)(w_lds + k * KMAX) = w0; *(f32x4*)(w_lds + k * KMAX + 4) = w1;
-    }
-    __syncthreads();
+            for (int c = 0; c < 4; ++c) { if (c >= a.classes) w0[c] = 0.f; if (c + 4 >= a.classes) w1[c] = 0.f; }
+            *(f32x4*)(w_lds + k * KMAX) = w0; *(f32x4*)(w_lds + k * KMAX + 4) = w1;
+        }
+    };
 
     // ---- logits: LPR lanes per row, each over an interleaved slice of the features ----
     constexpr int LPR = 256 / HR;
@@ -261,12 +269,17 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     float l[KMAX];
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) l[c] = 0.f;
-    for (int kk = 0; kk < a.feat / LPR; ++kk) {
-        const int k = kk * LPR + part;
-        const float fv = f_lds[r * LDF + k];
-        const f32x4 w0 = *(const f32x4*)(w_lds + k * KMAX), w1 = *(const f32x4*)(w_lds + k * KMAX + 4);
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch) __syncthreads();                   // every thread is done with the previous chunk
+        load_chunk(ch * CH);
+        __syncthreads();
+        for (int kk = 0; kk < CH / LPR; ++kk) {
+            const int k = kk * LPR + part;
+            const float fv = f_lds[r * LDF + k];
+            const f32x4 w0 = *(const f32x4*)(w_lds + k * KMAX), w1 = *(const f32x4*)(w_lds + k * KMAX + 4);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { l[c] = fmaf(fv, w0[c], l[c]); l[4 + c] = fmaf(fv, w1[c], l[4 + c]); }
+            for (int c = 0; c < 4; ++c) { l[c] = fmaf(fv, w0[c], l[c]); l[4 + c] = fmaf(fv, w1[c], l[4 + c]); }
+        }
     }
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
@@ -346,28 +359,33 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
         for (int rr = 0; rr < HR; ++rr) s += dl_lds[rr * KMAX + t];
         part_row[a.off_db + t] = s;
     }
-    for (int j = t; j < a.feat; j += 256) {
-        float wj[KMAX], dw[KMAX];
+    T* dpre = (T*)a.dpre + (long)seg * a.dpre_bs;
+    // the last chunk is still in LDS: walk the chunks backwards and reload only the others
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        const int c0 = ch * CH;
+        if (ch != nch - 1) { __syncthreads(); load_chunk(c0); __syncthreads(); }
+        for (int j = t; j < CH && c0 + j < a.feat; j += 256) {
+            float wj[KMAX], dw[KMAX];
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) { wj[c] = w_lds[j * KMAX + c]; dw[c] = 0.f; }
-        float dbf = 0.f;
-        T* dpre = (T*)a.dpre + (long)seg * a.dpre_bs;
-        for (int rr = 0; rr < HR; ++rr) {
-            const float fv = f_lds[rr * LDF + j];
-            const f32x4 d0 = *(const f32x4*)(dl_lds + rr * KMAX), d1 = *(const f32x4*)(dl_lds + rr * KMAX + 4);
-            float dfe = 0.f;
+            for (int c = 0; c < KMAX; ++c) { wj[c] = w_lds[j * KMAX + c]; dw[c] = 0.f; }
+            float dbf = 0.f;
+            for (int rr = 0; rr < HR; ++rr) {
+                const float fv = f_lds[rr * LDF + j];
+                const f32x4 d0 = *(const f32x4*)(dl_lds + rr * KMAX), d1 = *(const f32x4*)(dl_lds + rr * KMAX + 4);
+                float dfe = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                dfe = fmaf(d0[c], wj[c], dfe); dfe = fmaf(d1[c], wj[4 + c], dfe);
-                dw[c] = fmaf(fv, d0[c], dw[c]); dw[4 + c] = fmaf(fv, d1[c], dw[4 + c]);
+                for (int c = 0; c < 4; ++c) {
+                    dfe = fmaf(d0[c], wj[c], dfe); dfe = fmaf(d1[c], wj[4 + c], dfe);
+                    dw[c] = fmaf(fv, d0[c], dw[c]); dw[4 + c] = fmaf(fv, d1[c], dw[4 + c]);
+                }
+                const float dp = (fv > 0.f) ? dfe : 0.f;
+                if (row_blk + rr < a.rows) dpre[(long)(row_blk + rr) * a.ldd + c0 + j] = Elem<T>::from_f32(dp);
+                dbf += dp;
             }
-            const float dp = (fv > 0.f) ? dfe : 0.f;
-            if (row_blk + rr < a.rows) dpre[(long)(row_blk + rr) * a.ldd + j] = Elem<T>::from_f32(dp);
-            dbf += dp;
+            *(f32x4*)(part_row + (long)(c0 + j) * KMAX) = (f32x4){dw[0], dw[1], dw[2], dw[3]};
+            *(f32x4*)(part_row + (long)(c0 + j) * KMAX + 4) = (f32x4){dw[4], dw[5], dw[6], dw[7]};
+            part_row[a.off_dbf + c0 + j] = dbf;
         }
-        *(f32x4*)(part_row + (long)j * KMAX) = (f32x4){dw[0], dw[1], dw[2], dw[3]};
-        *(f32x4*)(part_row + (long)j * KMAX + 4) = (f32x4){dw[4], dw[5], dw[6], dw[7]};
-        part_row[a.off_dbf + j] = dbf;
     }
 }
 
@@ -565,14 +583,17 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     }
 }
 
-__global__ void noise_debug_kernel(uint64_t seed, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0,
-                                   int rows, int cols, float* out) {
-    const int col = blockIdx.x * 64 + threadIdx.x;
-    const int r4 = blockIdx.y * 4;
-    if (col >= cols) return;
-    float n[4];
-    normal4(noise_key(seed, site * 256u + seg, step), (row0 + (uint32_t)r4) >> 2, (uint32_t)col, n);
-    for (int j = 0; j < 4; ++j) if (r4 + j < rows) out[(long)(r4 + j) * cols + col] = n[j];
+__global__ __launch_bounds__(64) void noise_debug_kernel(uint64_t seed, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0,
+                                                         int rows, int cols, float* out) {
+    const int lane = threadIdx.x, lc = lane & 31, lh = lane >> 5;
+    const int rbase = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const uint32_t rh = noise_rowhash(noise_key(seed, site * 256u + seg, step), row0 + (uint32_t)(rbase + lc));
+    const i32x16 nz = noise_block(rh, (uint32_t)c0 >> 5, lane, hadamard_frag(lane));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < rows && c0 + lc < cols) out[(long)row * cols + c0 + lc] = NOISE_SCALE * (float)nz[r];
+    }
 }
 
 }  // namespace
@@ -587,7 +608,7 @@ __global__ void noise_debug_kernel(uint64_t seed, uint32_t site, uint32_t seg, u
 int launch_stage(int bf16, const StageArgs& a, hipStream_t s) {
     int maxc = 0, maxr = 0;
     for (int i = 0; i < a.nseg; ++i) { maxc = max(maxc, a.s[i].cols_pad); maxr = max(maxr, a.s[i].rows); }
-    dim3 grid(ceil_div(maxc, 256), ceil_div(maxr, 16), a.nseg);
+    dim3 grid(ceil_div(maxc, 128), ceil_div(maxr, 128), a.nseg);
     LAUNCH_T(stage_kernel, grid, dim3(256), 0, s, a);
     RET_LAUNCH;
 }
@@ -615,8 +636,9 @@ int init_kernel_attributes() {
 }
 
 int launch_head(int bf16, const HeadArgs& a, hipStream_t s) {
-    if (a.feat > 256 || (a.feat % 8) != 0 || a.classes > KMAX) return -3;
-    const size_t smem = sizeof(float) * ((size_t)HR * (a.feat + 8) + (size_t)a.feat * KMAX + HR * KMAX + 16);
+    const int ch = std::min(a.feat, HEAD_CHUNK);
+    if ((a.feat % 64) != 0 || a.classes > KMAX) return -3;
+    const size_t smem = sizeof(float) * ((size_t)HR * (ch + 8) + (size_t)ch * KMAX + HR * KMAX + 16);
     dim3 grid(ceil_div(a.rows, HR), a.nseg);
     LAUNCH_T(head_kernel, grid, dim3(256), smem, s, a);
     RET_LAUNCH;
@@ -647,7 +669,7 @@ int launch_adam(const AdamArgs& a, hipStream_t s) {
 
 int launch_noise_debug(uint64_t seed, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,
                        float* out, hipStream_t s) {
-    MRGAN_LAUNCH(noise_debug_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 4)), dim3(64), 0, s, seed, site, seg,
+    MRGAN_LAUNCH(noise_debug_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(64), 0, s, seed, site, seg,
                        step, row0, rows, cols, out);
     RET_LAUNCH;
 }

@@ -61,16 +61,27 @@ template <> struct Elem<__bf16> {
 };
 
 // ---------------------------------------------------------------------------------------
-// Layer-noise / z generator: a counter hash + Box-Muller.  Restated bit-for-bit in
-// oracle/mrgan_oracle.py (device_normal).  One call yields the four normals of rows 4q..4q+3 at one
-// column of one noise site in one sub-step:
-//     key = mix(seed, site*256+seg, sub-step)                       (wave-uniform)
-//     a   = mix32(key ^ q*0x9E3779B1)                               (per row group)
-//     x0  = mix32(a ^ col*0x85EBCA77),  x1 = mix32(rotl16(a) + col*0xC2B2AE3D + 1)
-// and the four 16-bit halves of (x0, x1) are the uniforms of two Box-Muller pairs.  mix32 is the
-// "lowbias32" integer finaliser; ~5 VALU ops per normal for the bits (Philox4x32-10: ~25), which
-// matters because the forward GEMM epilogues draw one normal per output element.
+// Layer-noise / z generator: counter hash -> random bytes -> +-1 Hadamard mix ON THE MATRIX CORE.
+// Restated bit-for-bit in oracle/mrgan_oracle.py (device_normal); every step is integer arithmetic, so
+// the device and the restatement agree exactly.
+//
+// The normal at (global row R, column C) of one noise site in one sub-step:
+//     key     = mix(seed, site*256+seg, sub-step)                          (wave-uniform)
+//     rowhash = mix32(key + R * 0x9E3779B1)
+//     w[m]    = mix32(rowhash ^ ((C>>5)*8 + m) * 0x85EBCA77) | 0x01010101,  m = 0..7
+//               -> 32 signed ODD bytes a[k] in {-127, -125, .., 127} (symmetric: mean exactly 0), k = 4m + t
+//     s       = sum_k a[k] * H[k][C&31],   H[k][j] = (-1)^popcount(k & j)  (32 x 32 Sylvester-Hadamard)
+//     n       = s / sqrt(32 * (128^2 - 1) / 3)
+// i.e. each normal is a signed sum of 32 independent uniform bytes (Irwin-Hall: excess kurtosis -0.0375,
+// support +-9.72 sigma).  The 32 columns of a block share their row's bytes through orthogonal sign patterns:
+// exactly uncorrelated, unit variance.
+// One v_mfma_i32_32x32x32_i8 turns 4 hash words per lane into the 16 normals a lane needs for a 32x32
+// accumulator tile, already in the accumulator's own lane layout: ~4.5 VALU issue slots per normal
+// (the Box-Muller generator of round 1 spent ~17) and the matrix pipe is otherwise idle in an epilogue.
 // ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
@@ -78,22 +89,34 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 __device__ __forceinline__ uint32_t noise_key(uint64_t seed, uint32_t site_seg, uint32_t step) {
     return mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) ^ mix32(step ^ mix32(site_seg))));
 }
-__device__ __forceinline__ float u16_01(uint32_t v) { return fmaf((float)v, 1.0f / 65536.0f, 0.5f / 65536.0f); }   // (v+0.5)/2^16, inside (0,1)
+constexpr float NOISE_SCALE = 2.3921528308e-03f;      // 1 / sqrt(32 * (128^2 - 1) / 3)
 
-// n[0..3]: standard normals for rows 4q..4q+3 at column col
-__device__ __forceinline__ void normal4(uint32_t key, uint32_t q, uint32_t col, float n[4]) {
-    const uint32_t a = mix32(key ^ (q * 0x9E3779B1u));
-    const uint32_t x0 = mix32(a ^ (col * 0x85EBCA77u));
-    const uint32_t x1 = mix32(((a << 16) | (a >> 16)) + col * 0xC2B2AE3Du + 1u);
-    // r = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u); v_sin/v_cos take revolutions
-    // raw v_sqrt_f32 (1 ulp): the IEEE-exact sqrtf expands to ~15 instructions
-    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u16_01(x0 & 0xFFFFu)));
-    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u16_01(x1 & 0xFFFFu)));
-    const float t0 = u16_01(x0 >> 16), t1 = u16_01(x1 >> 16);
-    n[0] = r0 * __builtin_amdgcn_cosf(t0);
-    n[1] = r0 * __builtin_amdgcn_sinf(t0);
-    n[2] = r1 * __builtin_amdgcn_cosf(t1);
-    n[3] = r1 * __builtin_amdgcn_sinf(t1);
+// B operand of the noise MFMA: lane (j = lane&31, h = lane>>5) holds H[k][j] for k = 16h .. 16h+15 as bytes +1 / -1
+__device__ __forceinline__ i32x4 hadamard_frag(int lane) {
+    const uint32_t j = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
+    i32x4 f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t k = 16u * h + 4u * m + t;
+            w |= ((__builtin_popcount(k & j) & 1) ? 0xFFu : 0x01u) << (8 * t);
+        }
+        f[m] = (int)w;
+    }
+    return f;
+}
+__device__ __forceinline__ uint32_t noise_rowhash(uint32_t key, uint32_t row) { return mix32(key + row * 0x9E3779B1u); }
+// raw sums s of the 32 x 32 block (rows: the 32 rows whose hashes the lanes l&31 carry; columns 32*cblk ..) in the MFMA
+// accumulator layout: register r of lane l = (row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31)
+__device__ __forceinline__ i32x16 noise_block(uint32_t rowhash, uint32_t cblk, int lane, const i32x4 hfrag) {
+    const uint32_t m0 = cblk * 8u + 4u * ((uint32_t)lane >> 5);
+    i32x4 a;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = (int)(mix32(rowhash ^ ((m0 + (uint32_t)m) * 0x85EBCA77u)) | 0x01010101u);
+    const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, hfrag, z, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -185,7 +185,6 @@ int dw_tiles(const Dense& L) { return ceil_div(L.Kp, 128) * ceil_div(L.Np, 128);
 int validate(const mrgan_config& c) {
     if (c.d_in < 1 || c.batch < 1) return fail(-1, "d_in and batch must be positive");
     if (c.num_classes < 2 || c.num_classes > KMAX) return fail(-1, "num_classes must be in [2,%d]", KMAX);
-    if (pad64(c.d_hidden[4]) > 256) return fail(-1, "feature layer wider than 256 is not supported by the fused loss head");
     if (c.dtype != MRGAN_F32 && c.dtype != MRGAN_BF16) return fail(-1, "unknown dtype");
     if (c.world < 1 || c.rank < 0 || c.rank >= c.world) return fail(-1, "bad rank/world");
     if (c.world > 1 && (c.batch % 4) != 0) return fail(-1, "data-parallel shards need batch %% 4 == 0 (noise row groups)");

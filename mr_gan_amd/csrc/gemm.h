@@ -145,9 +145,21 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         else if (DYN && e.mask) mask = e.mask + (long)batch * e.mask_bs;
         const T* hprev = e.h ? (const T*)e.h + (long)batch * e.h_bs : nullptr;
         const bool noisy = EPI == EPI_FWD && (DYN ? e.sigma > 0.f : (VAR & VAR_NOISE) != 0);
-        uint32_t nkey = 0;
-        if (noisy) nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)(batch * e.seg_step),
-                                    (pf ? pf->iter : (e.st ? e.st->iter : 0u)) + (uint32_t)batch * e.iter_step);
+        // GaussianNoise of the NEXT layer's input (mr_gan.py:120-126), drawn per 32x32 accumulator tile by one integer
+        // MFMA (common.h): the lane l&31 carries the hash of row rsub + (l&31), the result arrives in accumulator layout
+        uint32_t rowhash[MR];
+        i32x4 hfrag = {0, 0, 0, 0};
+        const float sigs = e.sigma * NOISE_SCALE;
+        if constexpr (EPI == EPI_FWD) {
+            if (noisy) {
+                const uint32_t nkey = noise_key(e.seed, e.site * 256u + e.seg0 + (uint32_t)(batch * e.seg_step),
+                                                (pf ? pf->iter : (e.st ? e.st->iter : 0u)) + (uint32_t)batch * e.iter_step);
+                hfrag = hadamard_frag(lane);
+#pragma unroll
+                for (int mi = 0; mi < MR; ++mi)
+                    rowhash[mi] = noise_rowhash(nkey, e.row0 + (uint32_t)(row_blk + (wm * MR + mi) * 32 + lc));
+            }
+        }
 
         // activated values for the column-sum pass below: ordinary registers, so a launch without column sums never
         // moves them back into the accumulator file
@@ -162,7 +174,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                 if (pf) bias = pf->bias[ni];
                 else if (colvalid && e.bias) bias = e.bias[col];
             }
-            const float sig = (noisy && colvalid) ? e.sigma : 0.f;
+            const float sig = (noisy && colvalid) ? sigs : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) {
                 const int rsub = row_blk + (wm * MR + mi) * 32;            // first row of this 32x32 sub-tile
@@ -172,13 +184,13 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                     if (pf) mbits = pf->mbits[mi][ni];
                     else if (act == ACT_RELU && colin && rsub < M) mbits = mask[mword];
                 }
+                i32x16 nzs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (EPI == EPI_FWD) {
+                    if (noisy) nzs = noise_block(rowhash[mi], (uint32_t)col >> 5, lane, hfrag);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r4 = rsub + 4 * lh + 8 * q;
-                    float nz[4] = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (EPI == EPI_FWD) {
-                        if (noisy) normal4(nkey, (e.row0 + (uint32_t)r4) >> 2, (uint32_t)col, nz);
-                    }
                     float o4[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -194,7 +206,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             } else if (act == ACT_SOFTPLUS) {
                                 v = colvalid ? (fast_math ? softplus_fast(v) : softplus_f(v)) : 0.f;
                             }
-                            o = noisy ? fmaf(sig, nz[j], v) : v;
+                            o = noisy ? fmaf(sig, (float)nzs[r], v) : v;
                         } else {
                             // rows >= M and padding columns arrive as exact zeros (zero-filled operands / zero weights)
                             if (act == ACT_RELU)        // all-ones / zero from the mask bit, applied to the float's bits

@@ -63,11 +63,14 @@ class GenArgs(C.Structure):
 _lib = None
 
 
-def load_library():
-    """Load the HIP library; raises (never falls back) when it is absent."""
-    global _lib
+def load_library(path=None):
+    """Load the HIP library; raises (never falls back) when it is absent.  `path` (first call only) selects another build
+    of the same library, e.g. the diagnostic one with in-kernel stamps (make STAMPS=1)."""
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    if path is not None:
+        LIB_PATH = path
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libmrgan_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -307,6 +307,163 @@ class MRGANOracle(object):
 
 
 # ----------------------------------------------------------------------------------------
+# Device-dataflow mirror: the SAME algebra as MRGANOracle, evaluated in the order and with the storage roundings of
+# the HIP engine (mr_gan_amd/csrc/engine.hip), so that a reduced-precision engine can be held to a tight tolerance.
+#   quantize=None   : no rounding anywhere -> must agree with MRGANOracle to fp64 round-off (tests/test_oracle.py),
+#                     which pins the mirror's structure to the autograd-checked restatement.
+#   quantize='bf16' : every tensor the engine STORES as bf16 is rounded (RNE) where the engine rounds it: GEMM weight
+#                     copies, z, the noisy layer inputs, h1 / BN(h1) / h2, every dpre / dX activation.  Batch
+#                     statistics, bias gradients and column sums come from the unrounded fp32 values, as on the device;
+#                     the 250x6 loss head uses the fp32 master W6.
+#   quantize='fp8'  : see Fp8Spec below (e4m3 forward operands, e5m2 gradients, per-tensor power-of-two scales).
+# ----------------------------------------------------------------------------------------
+def bf16_round(x):
+    """round-to-nearest-even to bfloat16, returned in x's dtype"""
+    x = np.asarray(x)
+    f = np.ascontiguousarray(x, dtype=np.float32)
+    u = f.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(x.dtype if x.dtype.kind == 'f' else np.float32)
+
+
+def _ident(x):
+    return x
+
+
+class MRGANMirror(object):
+    """train_batch_disc / train_batch_gen in the engine's dataflow.  Same call signatures as MRGANOracle."""
+
+    def __init__(self, g, d, quantize=None, sigmas=D_SIGMAS, unlabeled_weight=UNLABELED_WEIGHT):
+        self.g = [np.array(p) for p in g]
+        self.d = [np.array(p) for p in d]
+        self.adam = Adam(self.g, self.d)
+        self.sigmas = sigmas
+        self.uw = unlabeled_weight
+        self.quantize = quantize
+        self.q = {None: _ident, 'bf16': bf16_round}[quantize]
+
+    # ---- generator forward (engine: stage z -> G1+stats -> bn_apply -> G2 -> G3(+noise)) ----
+    def _gen_fwd(self, z, n0):
+        q = self.q
+        W1, b1, gamma, beta, W2, b2, W3, b3 = self.g
+        zq = q(z)
+        h1 = softplus(zq @ q(W1) + b1)
+        B = h1.shape[0]
+        mu = h1.sum(axis=0) / B
+        var = np.maximum((h1 * h1).sum(axis=0) / B - mu * mu, 0.0)          # bn_apply_kernel: E[h^2] - E[h]^2 of the unrounded h
+        rstd = 1.0 / np.sqrt(var + BN_EPS)
+        h1q = q(h1)
+        scale = gamma * rstd
+        hbn = q(h1q * scale + (beta - mu * scale))
+        h2q = q(softplus(hbn @ q(W2) + b2))
+        x = h2q @ q(W3) + b3
+        xin = q(x + np.asarray(self.sigmas[0], x.dtype) * n0) if n0 is not None else q(x)
+        return xin, dict(zq=zq, h1q=h1q, mu=mu, rstd=rstd, hbn=hbn, h2q=h2q, B=B)
+
+    # ---- discriminator forward over one segment whose (noisy, rounded) first-layer input is xin0 ----
+    def _disc_fwd(self, xin0, noise):
+        q = self.q
+        nl = len(self.d) // 2
+        xin, masks = [xin0], []
+        a = None
+        for l in range(nl - 1):
+            pre = xin[l] @ q(self.d[2 * l]) + self.d[2 * l + 1]
+            a = relu(pre)
+            masks.append(a > 0)
+            if l < nl - 2:
+                xin.append(q(a + np.asarray(self.sigmas[l + 1], a.dtype) * noise[l + 1]) if noise is not None else q(a))
+        feat_q = q(a)
+        return dict(xin=xin, masks=masks, feat=a, feat_q=feat_q)
+
+    def _stage(self, x, n0):
+        return self.q(x + np.asarray(self.sigmas[0], x.dtype) * n0)
+
+    # dX chain from dpre of the feature layer down to layer `stop`; returns the list of (rounded) dpre_l and bias sums
+    def _disc_bwd(self, c, dpre_top, want_bias):
+        q = self.q
+        nl = len(self.d) // 2
+        dpre = [None] * (nl - 1)
+        db = [None] * (nl - 1)
+        dpre[nl - 2] = dpre_top
+        for l in range(nl - 2, 0, -1):
+            v = (dpre[l] @ q(self.d[2 * l]).T) * c['masks'][l - 1]
+            if want_bias:
+                db[l - 1] = v.sum(axis=0)
+            dpre[l - 1] = q(v)
+        return dpre, db
+
+    def disc_grads(self, x_lab, labels, x_unl, z, n_lab, n_unl, n_fake):
+        q = self.q
+        nl = len(self.d) // 2
+        xf, _ = self._gen_fwd(z, n_fake[0])
+        segs = [self._disc_fwd(self._stage(x_lab, n_lab[0]), n_lab), self._disc_fwd(self._stage(x_unl, n_unl[0]), n_unl),
+                self._disc_fwd(xf, n_fake)]
+        W6, b6 = self.d[-2], self.d[-1]
+        logits = [c['feat_q'] @ W6 + b6 for c in segs]
+        out = disc_losses(logits[0], labels, logits[1], logits[2])
+        dls = disc_loss_grads(logits[0], labels, logits[1], logits[2], self.uw)
+        grads = [np.zeros_like(p) for p in self.d]
+        for c, dl in zip(segs, dls):
+            grads[-2] += c['feat_q'].T @ dl
+            grads[-1] += dl.sum(axis=0)
+            dp = (dl @ W6.T) * (c['feat_q'] > 0)
+            grads[2 * (nl - 2) + 1] += dp.sum(axis=0)
+            dpre, db = self._disc_bwd(c, q(dp), True)
+            for l in range(nl - 1):
+                grads[2 * l] += c['xin'][l].T @ dpre[l]
+                if l < nl - 2:
+                    grads[2 * l + 1] += db[l]
+        return out, grads, dict(l_lab=logits[0], l_unl=logits[1], l_fake=logits[2])
+
+    def disc_step(self, *a, **k):
+        out, grads, _ = self.disc_grads(*a, **k)
+        self.adam.apply(self.d, grads, 'd')
+        return out
+
+    def gen_grads(self, x_unl, z, n_fake, n_real):
+        q = self.q
+        W1, b1, gamma, beta, W2, b2, W3, b3 = self.g
+        xf, gc = self._gen_fwd(z, n_fake[0])
+        cf = self._disc_fwd(xf, n_fake)
+        cr = self._disc_fwd(self._stage(x_unl, n_real[0]), n_real)
+        B, J = cf['feat'].shape
+        diff = cf['feat'].sum(axis=0) / B - cr['feat'].sum(axis=0) / B          # moments of the unrounded features
+        loss = np.mean(diff * diff)
+        gj = (2.0 / (J * B)) * diff
+        dpre, _ = self._disc_bwd(cf, q(np.where(cf['masks'][-1], gj, 0.0)), False)
+        v = dpre[0] @ q(self.d[0]).T                                              # d loss / d x_fake (noise is additive)
+        db3 = v.sum(axis=0)
+        dxf = q(v)
+        dW3 = gc['h2q'].T @ dxf
+        v = (dxf @ q(W3).T) * (-np.expm1(-gc['h2q']))                             # softplus'(pre) = 1 - exp(-h)
+        db2 = v.sum(axis=0)
+        dpre2 = q(v)
+        dW2 = gc['hbn'].T @ dpre2
+        v = dpre2 @ q(W2).T
+        xh = (gc['h1q'] - gc['mu']) * gc['rstd']
+        dbeta = v.sum(axis=0)
+        dgamma = (v * xh).sum(axis=0)
+        d = q(v)
+        dh = (gamma * gc['rstd'] / B) * (B * d - dbeta - xh * dgamma)
+        o = dh * (-np.expm1(-gc['h1q']))
+        db1 = o.sum(axis=0)
+        dW1 = gc['zq'].T @ q(o)
+        return loss, [dW1, db1, dgamma, dbeta, dW2, db2, dW3, db3], dict(f_fake=cf['feat'], f_real=cr['feat'])
+
+    def gen_step(self, *a, **k):
+        loss, grads, _ = self.gen_grads(*a, **k)
+        self.adam.apply(self.g, grads, 'g')
+        return loss
+
+    def predict_logits(self, x):
+        c = self._disc_fwd(self.q(x), None)
+        return c['feat_q'] @ self.d[-2] + self.d[-1]
+
+    def test_error(self, x, labels):
+        return np.mean(np.argmax(self.predict_logits(x), axis=1) != labels)
+
+
+# ----------------------------------------------------------------------------------------
 # data prologue and epoch staging (mr_gan.py:96-107, :189-202) -- restated for the host tests
 # ----------------------------------------------------------------------------------------
 def standard_scale(X_train, X_test):
@@ -333,11 +490,13 @@ def tiled_permutation(rng_perm, n_pool, n_total):
 
 
 # ----------------------------------------------------------------------------------------
-# The build's device noise generator, restated (mr_gan_amd/csrc/common.h: mix32 / noise_key / normal4):
-# a counter hash keyed by (seed, site*256+segment, sub-step); per (row>>2, column) it yields the four
-# normals of rows 4q..4q+3 at that column through two Box-Muller pairs on 16-bit uniforms.
+# The build's device noise generator, restated (mr_gan_amd/csrc/common.h: mix32 / noise_key / noise_rowhash /
+# noise_block): counter hash -> 32 odd signed bytes per (row, 32-column block) -> +-1 Sylvester-Hadamard mix (one
+# v_mfma_i32_32x32x32_i8 per 32x32 block on the device) -> scale.  Integer arithmetic throughout: bit-exact.
 # ----------------------------------------------------------------------------------------
 SITE_Z = 16     # generator input z; sites 0..4 are the GaussianNoise layers before dense 1..5
+NOISE_SCALE = 1.0 / np.sqrt(32.0 * (128.0 ** 2 - 1.0) / 3.0)
+_HADAMARD32 = np.array([[1 - 2 * (bin(k & j).count("1") & 1) for j in range(32)] for k in range(32)], dtype=np.int64)
 
 
 def mix32(x):
@@ -357,27 +516,22 @@ def noise_key(seed, site_seg, step):
     return mix32(lo ^ mix32(hi ^ mix32(np.uint32(step) ^ mix32(np.uint32(site_seg)))))
 
 
-def _u16_01(v):
-    return (v.astype(np.float64) + 0.5) * (1.0 / 65536.0)
+def device_noise_sums(seed, site, seg, step, rows, cols, row0=0):
+    """The integer sums s[rows, cols] behind device_normal (each a signed sum of 32 odd bytes)."""
+    nb = (cols + 31) // 32
+    key = noise_key(seed, site * 256 + seg, step)
+    with np.errstate(over='ignore'):
+        r = (np.arange(rows, dtype=np.uint32) + np.uint32(row0))
+        rowhash = mix32(key + r * np.uint32(0x9E3779B1))                                        # [rows]
+        m = np.arange(nb * 8, dtype=np.uint32) * np.uint32(0x85EBCA77)                          # word index cblk*8 + m
+        w = mix32(rowhash[:, None] ^ m[None, :]) | np.uint32(0x01010101)                        # [rows, nb*8]
+    # byte t of word m is a[k = 4m + t] (little endian), signed
+    a = np.ascontiguousarray(w).view(np.int8).reshape(rows, nb, 32).astype(np.int64)
+    s = a @ _HADAMARD32                                                                         # [rows, nb, 32]
+    return s.reshape(rows, nb * 32)[:, :cols]
 
 
 def device_normal(seed, site, seg, step, rows, cols, row0=0, dtype=np.float64):
-    """Standard normals [rows, cols] exactly as the HIP kernels draw them (up to the ulp-level
-    error of the device's log2/sqrt/sin/cos).  row0 = global index of the first row within its
-    segment (multiple of 4) -- used by data-parallel ranks."""
-    assert row0 % 4 == 0
-    nq = (rows + 3) // 4
-    key = noise_key(seed, site * 256 + seg, step)
-    q = (np.arange(nq, dtype=np.uint32) + np.uint32(row0 // 4))[:, None]
-    c = np.arange(cols, dtype=np.uint32)[None, :]
-    with np.errstate(over='ignore'):
-        a = mix32(key ^ (q * np.uint32(0x9E3779B1)))
-        x0 = mix32(a ^ (c * np.uint32(0x85EBCA77)))
-        x1 = mix32(((a << np.uint32(16)) | (a >> np.uint32(16))) + c * np.uint32(0xC2B2AE3D) + np.uint32(1))
-    out = np.empty((nq * 4, cols), dtype=np.float64)
-    for j, x in enumerate((x0, x1)):
-        r = np.sqrt(-2.0 * np.log(_u16_01(x & np.uint32(0xFFFF))))
-        th = 2.0 * np.pi * _u16_01(x >> np.uint32(16))
-        out[2 * j::4] = r * np.cos(th)
-        out[2 * j + 1::4] = r * np.sin(th)
-    return out[:rows].astype(dtype)
+    """Standard normals [rows, cols] exactly as the HIP kernels draw them.  row0 = global index of the first row
+    within its segment (data-parallel ranks)."""
+    return (device_noise_sums(seed, site, seg, step, rows, cols, row0) * NOISE_SCALE).astype(dtype)

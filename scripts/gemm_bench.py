@@ -25,7 +25,8 @@ SHAPES = [  # (name, op, m, n, k, nbatch, splits)
     ("dw  D3 512x256 /3B", 2, B, 256, 512, 3, 16),
     ("dw  D4 256x256 /3B", 2, B, 256, 256, 3, 16),
 ]
-lib = E.load_library()
+import os
+lib = E.load_library(os.environ.get("MRGAN_BENCH_LIB"))      # e.g. mr_gan_amd/lib/libmrgan_hip_stamps.so (make STAMPS=1)
 bits = [int(a) for a in sys.argv[1:]] or [0]
 print("%-22s %8s " % ("shape", "GFLOP") + " ".join("abl%-3d us / TF   " % b for b in bits))
 for name, op, m, n, k, nb, sp in SHAPES:

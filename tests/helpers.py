@@ -12,26 +12,28 @@ from oracle import mrgan_oracle as O
 SEED = 0x5EED5EED
 
 
-def layer_dims(D):
-    return (D,) + O.D_HIDDEN
+def layer_dims(D, d_hidden=O.D_HIDDEN):
+    return (D,) + tuple(d_hidden)
 
 
-def noise_set(seed, seg, step, B, D, row0=0, dtype=np.float64):
-    dims = layer_dims(D)
+def noise_set(seed, seg, step, B, D, row0=0, dtype=np.float64, d_hidden=O.D_HIDDEN):
+    dims = layer_dims(D, d_hidden)
     return [O.device_normal(seed, l, seg, step, B, dims[l], row0=row0, dtype=dtype) for l in range(5)]
 
 
-def draw_z(seed, step, B, row0=0, dtype=np.float64):
-    return O.device_normal(seed, O.SITE_Z, 0, step, B, O.NOISE_SIZE, row0=row0, dtype=dtype)
+def draw_z(seed, step, B, row0=0, dtype=np.float64, nz=O.NOISE_SIZE):
+    return O.device_normal(seed, O.SITE_Z, 0, step, B, nz, row0=row0, dtype=dtype)
 
 
 class Case(object):
     """A reproducible training problem + its oracle trajectory."""
 
-    def __init__(self, D=16, B=50, steps=3, seed=7, noise_seed=SEED, dtype=np.float64, device_z=False):
+    def __init__(self, D=16, B=50, steps=3, seed=7, noise_seed=SEED, dtype=np.float64, device_z=False,
+                 d_hidden=O.D_HIDDEN, g_hidden=O.G_HIDDEN):
         rng = np.random.default_rng(seed)
         self.D, self.B, self.steps, self.noise_seed = D, B, steps, noise_seed
-        g, d = O.init_params(D, seed=seed, dtype=dtype)
+        self.d_hidden, self.g_hidden = tuple(d_hidden), tuple(g_hidden)
+        g, d = O.init_params(D, seed=seed, dtype=dtype, g_hidden=self.g_hidden, d_hidden=self.d_hidden)
         # non-trivial biases / BN affine so every path carries signal
         g = [p + 0.05 * rng.standard_normal(p.shape).astype(dtype) for p in g]
         d = [p + 0.05 * rng.standard_normal(p.shape).astype(dtype) for p in d]
@@ -53,9 +55,9 @@ class Case(object):
         z = self.z1[t][sl] if self.z1 is not None else draw_z(self.noise_seed, it, nB, row0)
         return dict(x_lab=self.x_lab[t][sl].astype(self.dtype), labels=self.labels[t][sl],
                     x_unl=self.x_unl[t][sl].astype(self.dtype), z=np.asarray(z, self.dtype),
-                    n_lab=noise_set(self.noise_seed, 0, it, nB, self.D, row0, self.dtype),
-                    n_unl=noise_set(self.noise_seed, 1, it, nB, self.D, row0, self.dtype),
-                    n_fake=noise_set(self.noise_seed, 2, it, nB, self.D, row0, self.dtype))
+                    n_lab=noise_set(self.noise_seed, 0, it, nB, self.D, row0, self.dtype, self.d_hidden),
+                    n_unl=noise_set(self.noise_seed, 1, it, nB, self.D, row0, self.dtype, self.d_hidden),
+                    n_fake=noise_set(self.noise_seed, 2, it, nB, self.D, row0, self.dtype, self.d_hidden))
 
     def gen_inputs(self, t, it, rows=None, row0=0):
         B = self.B
@@ -63,11 +65,13 @@ class Case(object):
         nB = rows or B
         z = self.z2[t][sl] if self.z2 is not None else draw_z(self.noise_seed, it, nB, row0)
         return dict(x_unl=self.x_unl2[t][sl].astype(self.dtype), z=np.asarray(z, self.dtype),
-                    n_fake=noise_set(self.noise_seed, 0, it, nB, self.D, row0, self.dtype),
-                    n_real=noise_set(self.noise_seed, 1, it, nB, self.D, row0, self.dtype))
+                    n_fake=noise_set(self.noise_seed, 0, it, nB, self.D, row0, self.dtype, self.d_hidden),
+                    n_real=noise_set(self.noise_seed, 1, it, nB, self.D, row0, self.dtype, self.d_hidden))
 
-    def run_oracle(self):
-        orc = O.MRGANOracle(self.g0, self.d0)
+    def run_oracle(self, mirror=False, quantize=None):
+        """trajectory through the fp64 restatement, or (mirror=True) through the engine-dataflow mirror with the engine's
+        storage roundings (quantize = None | 'bf16' | 'fp8')"""
+        orc = O.MRGANMirror(self.g0, self.d0, quantize=quantize) if mirror else O.MRGANOracle(self.g0, self.d0)
         out = dict(disc=[], gen=[], logits0=orc.predict_logits(self.probe.astype(self.dtype)))
         for t in range(self.steps):
             out['disc'].append(orc.disc_step(**self.disc_inputs(t, orc.adam.iterations)))

@@ -18,13 +18,17 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _engine(D, B, dtype, flags=0, rank=0, world=1, seed=SEED):
+def _engine(D, B, dtype, flags=0, rank=0, world=1, seed=SEED, d_hidden=None, g_hidden=None):
     from mr_gan_amd import engine as E
     cfg = E.default_config(D, B)
     cfg.dtype = dtype
     cfg.seed = seed
     cfg.flags = flags
     cfg.rank, cfg.world = rank, world
+    for i, w in enumerate(d_hidden or ()):
+        cfg.d_hidden[i] = w
+    for i, w in enumerate(g_hidden or ()):
+        cfg.g_hidden[i] = w
     return E.Engine(cfg, DEV)
 
 
@@ -74,10 +78,14 @@ def test_gemm_products(dtype, tol, m, n, k):
 
 def test_device_noise_matches_restatement():
     eng = _engine(16, 52, 0)
-    for site, seg, step, rows, cols, row0 in [(0, 0, 0, 52, 16, 0), (3, 2, 7, 50, 250, 0), (16, 0, 5, 48, 100, 48)]:
+    # the generator is integer arithmetic (hash -> bytes -> i8 MFMA with a +-1 Hadamard operand) up to one fp32 scale:
+    # the device must reproduce the restatement's INTEGER sums exactly -- this is also what pins the operand lane maps of
+    # v_mfma_i32_32x32x32_i8 (a wrong k pairing or a transposed result changes the sums)
+    for site, seg, step, rows, cols, row0 in [(0, 0, 0, 52, 16, 0), (3, 2, 7, 50, 250, 0), (16, 0, 5, 48, 100, 48), (2, 1, 9, 70, 96, 37)]:
         got = eng.debug_noise(site, seg, step, rows, cols, row0).cpu().numpy()
-        want = O.device_normal(SEED, site, seg, step, rows, cols, row0=row0)
-        np.testing.assert_allclose(got, want, atol=2e-5, rtol=0)
+        sums = O.device_noise_sums(SEED, site, seg, step, rows, cols, row0=row0)
+        np.testing.assert_array_equal(np.rint(got.astype(np.float64) / O.NOISE_SCALE).astype(np.int64), sums)
+        np.testing.assert_allclose(got, O.device_normal(SEED, site, seg, step, rows, cols, row0=row0), rtol=2e-7, atol=0)
     big = eng.debug_noise(1, 1, 3, 2048, 512).cpu().numpy()
     assert abs(big.mean()) < 5e-3 and abs(big.std() - 1) < 5e-3
     eng.close()
@@ -110,17 +118,28 @@ def test_fp32_steps_match_oracle(D, B):
     _load(eng, case)
     got = _run_engine(eng, case)
     assert rel_err(got['logits0'], ref['logits0']) < 1e-5
+    # Everything after the first Adam update is bounded by what plain float32 arithmetic allows: the restatement evaluated
+    # in float32 on the same inputs deviates from its own fp64 run (rounding differences of near-zero gradients pass
+    # through Adam's m / (sqrt(v) + eps) as +-lr steps; tests/test_oracle.py shows > 1e-3 on logits at (800, 256)), so the
+    # engine gets max(the tight tolerance, 3 x that float32-vs-float64 deviation).  The first sub-step has no such slack.
+    r32 = Case(D=D, B=B, steps=3, dtype=np.float32).run_oracle()
     for t in range(case.steps):
-        np.testing.assert_allclose(got['disc'][t], ref['disc'][t], rtol=2e-4, atol=2e-5)
-        np.testing.assert_allclose(got['gen'][t], ref['gen'][t], rtol=2e-3, atol=1e-9)
+        dev = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(r32['disc'][t][:2], ref['disc'][t][:2]))
+        np.testing.assert_allclose(got['disc'][t][:2], ref['disc'][t][:2], rtol=2e-4 if t == 0 else max(2e-4, 3 * dev), atol=2e-5)
+        assert abs(got['disc'][t][2] - ref['disc'][t][2]) <= (1e-6 if t == 0 else 1.01 / B)
+        dev = abs(r32['gen'][t] - ref['gen'][t]) / abs(ref['gen'][t])
+        np.testing.assert_allclose(got['gen'][t], ref['gen'][t], rtol=max(2e-3, 3 * dev), atol=1e-9)
     # weights after three (D, G) pairs: pins the shared Adam counter (t = 2n-1 / 2n)
-    for i, (w, wr, w0) in enumerate(zip(got['d'], ref['d'], case.d0)):
-        assert update_rel_err(w, wr, w0) < 0.05, ("D", i)
-    for i, (w, wr, w0) in enumerate(zip(got['g'], ref['g'], case.g0)):
-        assert update_rel_err(w, wr, w0) < 0.05, ("G", i)
-    # logits of fresh rows after the three updates: fp32-vs-fp64 rounding differences pass through Adam's m / sqrt(v),
-    # which amplifies them for near-zero gradients; the wider layers of the 800-column case sit just above 1e-3
-    assert rel_err(got['logits'], ref['logits']) < (1e-3 if D <= 400 else 3e-3)
+    for i, (w, wr, w0, w32) in enumerate(zip(got['d'], ref['d'], case.d0, r32['d'])):
+        assert update_rel_err(w, wr, w0) < max(0.02, 3 * update_rel_err(w32, wr, w0)), ("D", i, update_rel_err(w, wr, w0), update_rel_err(w32, wr, w0))
+    for i, (w, wr, w0, w32) in enumerate(zip(got['g'], ref['g'], case.g0, r32['g'])):
+        assert update_rel_err(w, wr, w0) < max(0.02, 3 * update_rel_err(w32, wr, w0)), ("G", i, update_rel_err(w, wr, w0), update_rel_err(w32, wr, w0))
+    # logits of fresh rows after the three updates.  north_star's 1e-3 holds wherever plain float32 arithmetic allows it:
+    # the restatement evaluated in float32 on the same inputs deviates from its fp64 run by e32 (rounding differences of
+    # near-zero gradients pass through Adam's m / (sqrt(v) + eps); tests/test_oracle.py shows e32 > 1e-3 at (800, 256)),
+    # so the engine is bounded by max(1e-3, 2 * e32)
+    e32 = rel_err(r32['logits'], ref['logits'])
+    assert rel_err(got['logits'], ref['logits']) < max(1e-3, 2.0 * e32), (rel_err(got['logits'], ref['logits']), e32)
     assert eng.get_iterations() == 2 * case.steps
     eng.close()
 
@@ -137,7 +156,7 @@ def test_fp32_gradients_match_oracle():
     eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
     got = eng.get_slot(E.NET_D, 2)
     for i, (a, b) in enumerate(zip(got, gd)):
-        assert rel_err(a, b) < 2e-4, ("dD", i)
+        assert rel_err(a, b) < 2e-5, ("dD", i)          # measured ~5e-7 (scripts/parity_probe.py)
     out = eng.disc_step(da, E.D_ADAM, E.D_ADAM)
     np.testing.assert_allclose(out, (ll, lu, err), rtol=2e-4, atol=2e-5)
     orc.adam.apply(orc.d, gd, 'd')
@@ -146,7 +165,7 @@ def test_fp32_gradients_match_oracle():
     eng.gen_step(ga, E.G_GEN, E.G_TAIL, want_outputs=False)
     got = eng.get_slot(E.NET_G, 2)
     for i, (a, b) in enumerate(zip(got, gg)):
-        assert rel_err(a, b) < 2e-3, ("dG", i)
+        assert rel_err(a, b) < 2e-4, ("dG", i)          # measured ~1e-5 on db1 (cancellation), ~1e-6 elsewhere
     assert abs(eng.gen_step(ga, E.G_ADAM, E.G_ADAM) - loss) < 2e-3 * abs(loss) + 1e-9
     eng.close()
 
@@ -182,19 +201,107 @@ def test_eval_error_and_logits_large():
     eng.close()
 
 
-def test_bf16_steps_track_oracle():
-    case = Case(D=400, B=128, steps=2)
+def test_bf16_steps_match_bf16_mirror():
+    """Three (D, G) pairs in bf16 mode.  Tight assertions are against the oracle's bf16 MIRROR (same algebra, rounded to
+    bf16 exactly where the engine stores bf16: oracle/mrgan_oracle.py::MRGANMirror), which separates "bf16 rounding" from
+    "bug"; the loose assertions against the fp64 oracle say how far bf16 itself moves the trajectory."""
+    case = Case(D=400, B=128, steps=3)
     ref = case.run_oracle()
+    mir = case.run_oracle(mirror=True, quantize='bf16')
     eng = _engine(400, 128, 1)
     _load(eng, case)
     got = _run_engine(eng, case)
+    # (1) vs the bf16 mirror
+    assert rel_err(got['logits0'], mir['logits0']) < 2e-3
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-12)
+    for t in range(case.steps):
+        # first sub-step: same weights on both sides, tight.  Later sub-steps run on weights that went through Adam, whose
+        # early steps (~lr * sign(g)) amplify rounding-level gradient differences: bounded by a fraction of what bf16 itself
+        # does to the trajectory (mirror vs fp64)
+        for k in range(2):
+            slack = 0.0 if t == 0 else max(1e-2, 2.0 * rel(mir['disc'][t][k], ref['disc'][t][k]))
+            assert rel(got['disc'][t][k], mir['disc'][t][k]) < max(5e-4, slack), (t, k, got['disc'][t], mir['disc'][t], ref['disc'][t])
+        assert abs(got['disc'][t][2] - mir['disc'][t][2]) <= 2.01 / 128                          # train error: a row or two may flip
+        assert rel(got['gen'][t], mir['gen'][t]) < max(2e-3 if t == 0 else 2e-2, (0.6 if t == 0 else 2.0) * rel(mir['gen'][t], ref['gen'][t])), (t, got['gen'][t], mir['gen'][t], ref['gen'][t])
+    report = []
+    for name, ws, wm, wr_, w0 in (("D", got['d'], mir['d'], ref['d'], case.d0), ("G", got['g'], mir['g'], ref['g'], case.g0)):
+        for i, (w, wm_i, wr, wi) in enumerate(zip(ws, wm, wr_, w0)):
+            em, eo, emo = update_rel_err(w, wm_i, wi), update_rel_err(w, wr, wi), update_rel_err(wm_i, wr, wi)
+            report.append((name, i, em, eo, emo))
+    print("\nweights after 3 pairs, error / update size: vs mirror | vs fp64 | mirror vs fp64\n  " +
+          "\n  ".join("%s%-2d %.3f %.3f %.3f" % r for r in report))
+    for name, i, em, eo, emo in report:
+        # weights after three Adam updates, relative to the size of the update.  Early Adam steps are ~lr * sign(g), so elements
+        # whose gradients sit at rounding level step differently in ANY two evaluations; the engine must still be closer to the
+        # mirror than bf16 storage moves the mirror away from fp64
+        assert em < max(0.05, 0.9 * emo), (name, i, em, emo)
+        assert eo < 0.5, (name, i, eo)                       # (2) loose, vs fp64
+    assert rel_err(got['logits'], mir['logits']) < max(5e-3, 0.6 * rel_err(mir['logits'], ref['logits']))
+    # (2) vs the fp64 oracle (what bf16 storage costs)
     assert rel_err(got['logits0'], ref['logits0']) < 3e-2
     for t in range(case.steps):
         np.testing.assert_allclose(got['disc'][t][:2], ref['disc'][t][:2], rtol=3e-2, atol=3e-3)
         np.testing.assert_allclose(got['gen'][t], ref['gen'][t], rtol=0.15, atol=1e-8)
-    for i, (w, wr, w0) in enumerate(zip(got['d'], ref['d'], case.d0)):
-        assert update_rel_err(w, wr, w0) < 0.35, ("D", i)
     eng.close()
+
+
+def _grad_parity(D, B, dtype, quantize, tol, tol_loss, d_hidden=None, g_hidden=None, eval_first=True, frac=0.6):
+    """One D sub-step and one G sub-step in flat-gradient mode: all 20 gradient tensors and the four losses.
+
+    fp32 engine (quantize None): against the fp64 restatement at `tol`.
+    bf16 engine: against the oracle MIRROR, which rounds to bf16 exactly where the engine stores bf16.  What is left
+    between engine and mirror is fp32-vs-fp64 accumulation: a pre-activation is a sum of K signed terms, so its fp32 error
+    relative to its own size is ~sqrt(K) * 1e-7 ~ 1e-5 .. 1e-4, which flips the bf16 rounding of a few per cent of the stored
+    activations by one ulp (2^-8); ten chained layers and the cancellation in the bias gradients bring that to 1e-3 .. 2e-2
+    on the gradients (measured: scripts/parity_probe.py).  A wrong kernel shows up as an error against the mirror as
+    large as the error against the fp64 oracle, so the bound is: err(engine, mirror) < max(tol, frac * err(mirror, fp64)), frac = 0.6
+    -- the mirror must explain most of what bf16 does -- and, labelled loose, the direction against fp64."""
+    from mr_gan_amd import engine as E
+    kw = {}
+    if d_hidden:
+        kw = dict(d_hidden=d_hidden, g_hidden=g_hidden)
+    case = Case(D=D, B=B, steps=1, **kw)
+    mir = O.MRGANMirror(case.g0, case.d0, quantize=quantize)
+    orc = O.MRGANOracle(case.g0, case.d0)
+    (ll, lu, err), gd_m, _ = mir.disc_grads(**case.disc_inputs(0, 0))
+    _, gd_o, _ = orc.disc_grads(**case.disc_inputs(0, 0))
+    eng = _engine(D, B, dtype, flags=E.FLAG_FLAT_GRADS, **kw)
+    _load(eng, case)
+    if eval_first:
+        # an evaluation first: it fills ALL rows of the activation buffers (also the padding rows of a ragged batch),
+        # which the training step afterwards must tolerate
+        rs = np.random.RandomState(5)
+        eng.eval_error(_t(rs.randn(3 * 128 + 7, D).astype(np.float32)), _t(rs.randint(0, 6, size=3 * 128 + 7), torch.int32))
+    da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]), _t(case.z1[0]))
+    eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
+    report = []
+
+    def check(name, got, want_m, want_o, cos_min):
+        for i, (a, m, o) in enumerate(zip(got, want_m, want_o)):
+            em, eo, emo = frob_rel_err(a, m), frob_rel_err(a, o), frob_rel_err(m, o)
+            report.append("%s%-2d %.1e %.1e %.1e" % (name, i, em, eo, emo))
+            assert em < max(tol, frac * emo), (name + " vs mirror", i, em, emo)
+            if quantize:      # loose, vs fp64: ten chained contractions on bf16 operands keep the gradient's direction
+                assert cosine(a, o) > cos_min and eo < 0.25, (name + " vs fp64", i, cosine(a, o), eo)
+
+    check("dD", eng.get_slot(E.NET_D, 2), gd_m, gd_o, 0.995)
+    out = eng.disc_step(da, E.D_ADAM, E.D_ADAM)
+    np.testing.assert_allclose(out[:2], (ll, lu), rtol=tol_loss, atol=tol_loss * 0.1)
+    assert abs(out[2] - err) <= (1.01 / B if quantize else 1e-6)
+    # the G sub-step sees the D network AFTER its update: give engine, mirror and oracle the same updated weights
+    mir.adam.apply(mir.d, gd_m, 'd')
+    orc.d = [p.copy() for p in mir.d]
+    orc.adam.iterations = 1
+    eng.set_weights(E.NET_D, [p.astype(np.float32) for p in mir.d])
+    loss, gg_m, _ = mir.gen_grads(**case.gen_inputs(0, 1))
+    _, gg_o, _ = orc.gen_grads(**case.gen_inputs(0, 1))
+    ga = E.Engine.gen_args(_t(case.x_unl2[0]), _t(case.z2[0]))
+    eng.gen_step(ga, E.G_GEN, E.G_TAIL, want_outputs=False)
+    check("dG", eng.get_slot(E.NET_G, 2), gg_m, gg_o, 0.98)
+    lg = eng.gen_step(ga, E.G_ADAM, E.G_ADAM)
+    assert abs(lg - loss) < 5 * tol_loss * abs(loss) + 1e-12, (lg, loss)
+    eng.close()
+    print("\n(D=%d, B=%d) tensor: err vs mirror | vs fp64 | mirror vs fp64\n  " % (D, B) + "\n  ".join(report))
 
 
 @pytest.mark.parametrize("D,B", [(400, 50),       # the reference's ragged batch: the weight gradients reduce over the padding rows too
@@ -202,31 +309,20 @@ def test_bf16_steps_track_oracle():
                                  (3632, 512),     # all three modalities fused, one rank's shard of batch 4096
                                  (2432, 1024),    # config 4: contact-mic log-mel only
                                  (512, 4096)])    # config 2: the bench workload at full size
-def test_bf16_gradients_track_oracle(D, B):
-    from mr_gan_amd import engine as E
-    case = Case(D=D, B=B, steps=1)
-    orc = O.MRGANOracle(case.g0, case.d0)
-    _, gd, _ = orc.disc_grads(**case.disc_inputs(0, 0))
-    eng = _engine(D, B, 1, flags=E.FLAG_FLAT_GRADS)
-    _load(eng, case)
-    # an evaluation first: it fills ALL rows of the activation buffers (also the padding rows of a ragged batch),
-    # which the training step afterwards must tolerate
-    rs = np.random.RandomState(5)
-    eng.eval_error(_t(rs.randn(3 * 128 + 7, D).astype(np.float32)), _t(rs.randint(0, 6, size=3 * 128 + 7), torch.int32))
-    da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]), _t(case.z1[0]))
-    eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
-    # bf16 operands through up to ten chained contractions: the gradient direction must be preserved
-    # (cosine similarity), its length within 10 %
-    for i, (a, b) in enumerate(zip(eng.get_slot(E.NET_D, 2), gd)):
-        assert cosine(a, b) > 0.995 and frob_rel_err(a, b) < 0.1, ("dD", i, cosine(a, b), frob_rel_err(a, b))
-    orc.adam.apply(orc.d, gd, 'd')
-    eng.disc_step(da, E.D_ADAM, E.D_ADAM)
-    _, gg, _ = orc.gen_grads(**case.gen_inputs(0, 1))
-    ga = E.Engine.gen_args(_t(case.x_unl2[0]), _t(case.z2[0]))
-    eng.gen_step(ga, E.G_GEN, E.G_TAIL, want_outputs=False)
-    for i, (a, b) in enumerate(zip(eng.get_slot(E.NET_G, 2), gg)):
-        assert cosine(a, b) > 0.98 and frob_rel_err(a, b) < 0.2, ("dG", i, cosine(a, b), frob_rel_err(a, b))
-    eng.close()
+def test_bf16_gradients_match_bf16_mirror(D, B):
+    _grad_parity(D, B, 1, 'bf16', tol=3e-3, tol_loss=5e-4)
+
+
+def test_wide_stack_bf16_matches_bf16_mirror():
+    """BASELINE configs[4] geometry at one rank's share: hidden 4096 x 5 (generator 4096 x 2), D = 512, B = 8192 / 8 = 1024.
+    The layer widths are literals in the reference (mr_gan.py:111-128); mrgan_config generalises them."""
+    # (reductions of length 4096: the fp32 accumulation error, hence the residual against the mirror, is larger: frac 0.85)
+    _grad_parity(512, 1024, 1, 'bf16', tol=3e-3, tol_loss=5e-4, d_hidden=(4096,) * 5, g_hidden=(4096,) * 2, eval_first=False, frac=0.85)
+
+
+def test_wide_stack_fp32_matches_oracle():
+    """the same wide geometry through the fp32 MFMA path at a small batch, against the fp64 restatement"""
+    _grad_parity(64, 64, 0, None, tol=5e-5, tol_loss=1e-5, d_hidden=(1024, 512, 512, 320, 320), g_hidden=(320, 576), eval_first=False)
 
 
 # ---------------------------------------------------------------------------------------------------------

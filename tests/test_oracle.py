@@ -153,9 +153,78 @@ def test_noise_hash_properties():
 def test_device_normal_moments():
     n = O.device_normal(seed=1234, site=1, seg=2, step=7, rows=2048, cols=256)
     assert abs(n.mean()) < 0.01 and abs(n.std() - 1.0) < 0.01
-    assert abs((n ** 4).mean() - 3.0) < 0.05                      # Gaussian kurtosis
+    assert abs((n ** 4).mean() - (3.0 - 0.0375)) < 0.05            # Irwin-Hall(32) kurtosis: 3 - 1.2/32
     assert abs(np.corrcoef(n[:-1].ravel(), n[1:].ravel())[0, 1]) < 0.01     # neighbouring rows
     assert abs(np.corrcoef(n[:, :-1].ravel(), n[:, 1:].ravel())[0, 1]) < 0.01   # neighbouring columns
     # row-offset consistency (data-parallel shards draw the same global stream)
     n2 = O.device_normal(seed=1234, site=1, seg=2, step=7, rows=1024, cols=256, row0=1024)
     np.testing.assert_array_equal(n[1024:], n2)
+
+
+def test_device_normal_is_integer_exact_and_near_gaussian():
+    """The generator is integer arithmetic up to one final scale: the sums are even integers in [-4064, 4064], the 32
+    columns of a block are exactly orthogonal sign mixes of the same 32 odd bytes (sum of squares over a block row is
+    32 * sum a_k^2), and the marginal passes a Kolmogorov-Smirnov test against N(0,1)."""
+    from scipy import stats
+    s = O.device_noise_sums(seed=99, site=2, seg=1, step=5, rows=512, cols=96)
+    assert s.dtype.kind == 'i' and np.all(s % 2 == 0) and np.abs(s).max() <= 32 * 127
+    blk = s[:, 32:64].astype(np.int64)
+    e = (blk * blk).sum(axis=1)                       # Parseval: |H a|^2 = 32 |a|^2, a odd => a^2 = 1 mod 8
+    assert np.all(e % 32 == 0) and np.all((e // 32) % 8 == 0)
+    n = O.device_normal(seed=99, site=2, seg=1, step=5, rows=4096, cols=128).ravel()
+    assert stats.kstest(n[:100000], 'norm').pvalue > 1e-3
+    assert 4.0 < np.abs(n).max() < 9.73
+
+
+def test_bf16_round_is_rne():
+    x = np.array([1.0, 1.00390625, 1.01171875, -2.5, 3.14159, 1e-30, 65504.0, 0.0], dtype=np.float64)
+    want = torch.tensor(x, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    np.testing.assert_array_equal(O.bf16_round(x), want)
+    r = np.random.default_rng(0).standard_normal(10000) * 10.0 ** np.random.default_rng(1).integers(-6, 6, 10000)
+    np.testing.assert_array_equal(O.bf16_round(r), torch.tensor(r, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy())
+
+
+def test_mirror_without_rounding_equals_oracle():
+    """MRGANMirror restates the same algebra in the engine's dataflow (E[h^2]-mu^2 variance, softplus' from h, column
+    sums, per-segment accumulation).  With quantize=None it must reproduce the autograd-pinned MRGANOracle: this is
+    what ties the reduced-precision mirrors used by the GPU tests to the pinned restatement."""
+    g, d, x_lab, labels, x_unl, z, n1, n2, n3 = _rand_problem(D=40, B=12, seed=9)
+    a, b = O.MRGANOracle(g, d), O.MRGANMirror(g, d, quantize=None)
+    for step in range(2):
+        (la, ga, _), (lb, gb, _) = a.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3), b.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3)
+        np.testing.assert_allclose(la, lb, rtol=1e-12)
+        for u, v in zip(ga, gb):
+            np.testing.assert_allclose(u, v, rtol=1e-9, atol=1e-13)
+        a.adam.apply(a.d, ga, 'd'); b.adam.apply(b.d, gb, 'd')
+        (la, ga, _), (lb, gb, _) = a.gen_grads(x_unl, z, n1, n2), b.gen_grads(x_unl, z, n1, n2)
+        assert abs(la - lb) < 1e-12 * abs(la)
+        for u, v in zip(ga, gb):
+            np.testing.assert_allclose(u, v, rtol=1e-8, atol=1e-13)
+        a.adam.apply(a.g, ga, 'g'); b.adam.apply(b.g, gb, 'g')
+    np.testing.assert_allclose(a.predict_logits(x_lab), b.predict_logits(x_lab), rtol=1e-10)
+
+
+def test_bf16_mirror_stays_close_to_fp64_oracle():
+    """sanity of the quantised mirror: bf16 storage rounding moves the gradients of a small batch by <= ~10 %, not more"""
+    g, d, x_lab, labels, x_unl, z, n1, n2, n3 = _rand_problem(D=40, B=32, seed=4)
+    a, b = O.MRGANOracle(g, d), O.MRGANMirror(g, d, quantize='bf16')
+    (_, ga, _), (_, gb, _) = a.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3), b.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3)
+    for u, v in zip(ga, gb):
+        assert np.linalg.norm(u - v) < 0.25 * np.linalg.norm(u)
+    assert max(np.linalg.norm(u - v) / np.linalg.norm(u) for u, v in zip(ga, gb)) > 1e-4      # the rounding is really applied
+
+
+def test_fp32_arithmetic_alone_moves_post_adam_logits_by_more_than_1e3():
+    """Why tests/test_gpu_parity.py does not hold post-update logits to north_star's 1e-3 at (D, B) = (800, 256): the
+    restatement itself, evaluated in float32 instead of float64 on identical inputs, differs from its own fp64 run by
+    MORE than that after three Adam updates (early Adam moves a weight by ~lr * sign(g), so a gradient element at
+    rounding level may step the other way), while logits BEFORE any update agree to ~1e-6.  The GPU test therefore bounds
+    the engine's post-update deviation by a multiple of this float32-vs-float64 deviation, and holds the pre-update
+    logits to 1e-5."""
+    from tests.helpers import Case, rel_err
+    c64 = Case(D=800, B=256, steps=3)
+    c32 = Case(D=800, B=256, steps=3, dtype=np.float32)
+    r64, r32 = c64.run_oracle(), c32.run_oracle()
+    assert rel_err(r32['logits0'], r64['logits0']) < 1e-5
+    e = rel_err(r32['logits'], r64['logits'])
+    assert 1e-3 < e < 5e-2, e
