@@ -115,6 +115,14 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
  * sub-steps: the host skips the exchange after that G sub-step's G_GEN.  One D sub-step per hint. */
 int mrgan_pair_hint(mrgan_handle* h, int on);
 
+/* Launch-structure knobs of one handle (results stay within rounding; defaults are the measured best).  Call between
+ * steps, never inside a captured pair. */
+enum {
+    MRGAN_TUNE_CHAIN = 0         /* 1 (default where the layer widths allow): the 256-wide tail D3..D5 + loss head of the
+                                  * discriminator runs as row-block chain launches; 0: one launch per layer            */
+};
+int mrgan_set_tuning(mrgan_handle* h, int knob, int value);
+
 /* regions a data-parallel host all-reduces (sum) between phases; fp32 */
 enum {
     MRGAN_REGION_BN_STATS = 0,   /* after *_GEN : [2 segments][2][N1p]  sum h, sum h^2 of the generator BatchNorm
@@ -157,6 +165,7 @@ int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t ste
 int mrgan_debug_tr_probe(uint16_t* out1024_dev, mrgan_stream stream);
 /* timing experiments only (results become wrong): 2 = skip the GEMM epilogues, 4 = skip the GEMM main loops */
 int mrgan_debug_ablate(int bits);
+int mrgan_debug_buffer(mrgan_handle* h, int kind, int l, void** ptr_dev, int* rows_per_seg, int* ld, int* elem_size);
 /* average device time (us) of `reps` back-to-back launches of one bf16 product on scratch buffers:
  * op 0 forward (relu+noise+mask), 1 input-gradient (relu mask), 2 weight-gradient with `splits` slabs */
 int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, int reps, float* avg_us);

@@ -80,26 +80,39 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
     const int col = cbase + cg;
     if (col >= sg.cols_pad) return;
     const bool vec_ok = !sg.gen && (sg.ld & 3) == 0 && ((uintptr_t)sg.src & 15) == 0 && col + 7 < sg.cols;
-#pragma unroll 2
+    // source rows first, then every row's loads in flight together (a dependent index -> row chain per iteration is
+    // latency-bound: this kernel is 40 MB of traffic and must not take longer than a GEMM)
+    long srow[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = rbase + it * 4 + rl;
+        srow[it] = (!sg.gen && row < sg.rows) ? (sg.idx ? (long)sg.idx[o + row] : (o + row)) : 0;
+    }
+    float v[8][8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[it][c] = 0.f;
+        const int row = rbase + it * 4 + rl;
+        if (!sg.gen && row < sg.rows) {
+            const float* src = sg.src + srow[it] * sg.ld + col;
+            if (vec_ok) load8<float>(src, v[it]);
+            else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (col + c < sg.cols) v[it][c] = src[c];
+            }
+        }
+    }
+#pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int rr = it * 4 + rl, row = rbase + rr;
         if (row >= sg.rows) break;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (!sg.gen) {
-            const long sr = sg.idx ? (long)sg.idx[o + row] : (o + row);
-            const float* src = sg.src + sr * sg.ld + col;
-            if (vec_ok) load8<float>(src, v);
-            else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) if (col + c < sg.cols) v[c] = src[c];
-            }
-        }
         if (noisy && col < sg.cols) {
             const s16x8 nz = *(const s16x8*)&nlds[wave][rr][cg];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) if (col + c < sg.cols) v[c] = fmaf(sigs, (float)nz[c], v[c]);
+            for (int c = 0; c < 8; ++c) if (col + c < sg.cols) v[it][c] = fmaf(sigs, (float)nz[c], v[it][c]);
         }
-        store8<T>(out + (long)row * sg.ldo + col, v);
+        store8<T>(out + (long)row * sg.ldo + col, v[it]);
     }
 }
 

@@ -11,6 +11,7 @@
 
 #include "../../include/mrgan_abi.h"
 #include "aux_kernels.h"
+#include "chain.h"
 #include "gemm.h"
 
 using namespace mrgan;
@@ -111,6 +112,7 @@ struct mrgan_handle {
     float *cs_bn1, *cs_bn2, *cs_db[4], *cs_f, *cs_db3g, *cs_db2g, *cs_dbeta, *cs_dgamma, *db1g_part;
     float *head_part, *head_red, *loss_part; int head_stride, head_groups;
     int nblk_head, bnb_blocks;
+    bool chain_ok, use_chain; int chain_dbg;            // the 256-wide tail of the discriminator runs as row-block chain launches (gemm_chain.hip)
     AdamTile *tiles_g_dev, *tiles_d_dev; int ntiles_g, ntiles_d;
 
     // per-launch hipEvent profiling (bench.py's live roofline measurement)
@@ -286,9 +288,12 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->cs_dbeta = a.take<float>((size_t)tm * N1p); h->cs_dgamma = a.take<float>((size_t)tm * N1p);
     h->bnb_blocks = stat_row_blocks(B);
     h->db1g_part = a.take<float>((size_t)h->bnb_blocks * N1p);
-    h->nblk_head = 3 * ceil_div(B, HEAD_ROWS);
+    // the tail D3..D5 + head as chain launches: bf16, A image <= 512 columns, outputs <= 256 columns
+    h->chain_ok = h->bf16 && h->d[2].Kp <= CH_KMAX && h->d[2].Np <= CH_PW && h->d[3].Np <= CH_PW && h->d[4].Np <= CH_PW;
+    h->use_chain = h->chain_ok; h->chain_dbg = 0;
+    h->nblk_head = 3 * ceil_div(B, HEAD_ROWS);                            // capacity; the chain path fills 3 * ceil(B / 64) of them
     h->head_stride = (int)round_up(h->Fp * KMAX + KMAX + h->Fp, 64);      // dW6 | db6 | bias grad of the feature layer
-    h->head_groups = std::min(8, h->nblk_head);
+    h->head_groups = std::min(8, 3 * ceil_div(B, CH_ROWS));
     h->head_part = a.take<float>((size_t)h->nblk_head * h->head_stride);
     h->head_red = a.take<float>((size_t)h->head_groups * h->head_stride);
     h->loss_part = a.take<float>((size_t)h->nblk_head * 4);
@@ -513,6 +518,8 @@ int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, 
 }
 
 void* rowptr(mrgan_handle* h, void* base, long row, int ld) { return (char*)base + (size_t)row * ld * h->es; }
+// per-block partial rows the loss head wrote in this sub-step
+int head_blocks(const mrgan_handle* h) { return 3 * ceil_div(h->B, h->use_chain ? CH_ROWS : HEAD_ROWS); }
 
 int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t s) {
     AdamArgs a;
@@ -522,7 +529,7 @@ int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t 
     a.mode = mode; a.b1 = h->cfg.beta1; a.b2 = h->cfg.beta2; a.eps = h->cfg.adam_eps;
     a.st = h->state + h->cur;
     if (with_metrics) {
-        a.loss_part = h->loss_part; a.nloss_part = h->nblk_head; a.inv_rows = 1.0f / (float)h->Bg;
+        a.loss_part = h->loss_part; a.nloss_part = head_blocks(h); a.inv_rows = 1.0f / (float)h->Bg;
         a.step_out = h->step_out; a.accum = h->accum;
         a.flat_tail = h->flat_d + h->flat_d_n;
     }
@@ -577,8 +584,8 @@ int gen_fwd_tail(mrgan_handle* h, int nb, int fake_seg_slot, uint32_t fake_seg_i
 }
 
 // discriminator dense 1..5 over nb segments (learning phase 1: noise on)
-int disc_fwd_train(mrgan_handle* h, int nb, bool fm_sums, int x0_slot, hipStream_t s) {
-    for (int l = 0; l < 5; ++l) {
+int disc_fwd_train(mrgan_handle* h, int nb, bool fm_sums, int x0_slot, hipStream_t s, int l_end = 5) {
+    for (int l = 0; l < l_end; ++l) {
         const void* in = l == 0 ? rowptr(h, h->xin[0], (long)x0_slot * h->S, h->Dp) : h->xin[l];
         void* out = l < 4 ? h->xin[l + 1] : h->feat;
         const float sigma = l < 4 ? h->cfg.sigma[l + 1] : 0.f;
@@ -586,6 +593,67 @@ int disc_fwd_train(mrgan_handle* h, int nb, bool fm_sums, int x0_slot, hipStream
         CHK(dense_fwd(h, h->d[l], in, h->B, nb, out, ACT_RELU, sigma, (uint32_t)(l + 1), 0, h->mask[l], h->ldm[l],
                       (last && fm_sums) ? CS_SUM : CS_NONE, h->cs_f, nullptr, true, s));
     }
+    return 0;
+}
+
+// ---- row-block chain launches for the tail D3..D5 (+ head) of the discriminator (gemm_chain.hip) ----
+ChainOp chain_fwd_op(mrgan_handle* h, int l, int a_off, int o_off, bool fm_sums) {
+    const Dense& L = h->d[l];
+    ChainOp o;
+    memset(&o, 0, sizeof o);
+    o.kind = CH_OP_GEMM; o.K = L.Kp; o.N = L.Np; o.n_valid = L.N; o.W = L.W->wt16; o.a_off = a_off; o.o_off = o_off;
+    o.mode = CH_FWD_RELU; o.bias = L.b->p; o.sigma = l < 4 ? h->cfg.sigma[l + 1] : 0.f; o.site = (uint32_t)(l + 1);
+    o.out = (__bf16*)(l < 4 ? h->xin[l + 1] : h->feat); o.out_bs = (long)h->S * L.Np; o.ldo = L.Np;
+    o.mask = h->mask[l]; o.mask_bs = (long)(h->S / 32) * h->ldm[l] * 2; o.ldm = h->ldm[l];
+    if (fm_sums) { o.cs = h->cs_f; o.ldcs = L.Np; }
+    return o;
+}
+// dX of layer l: dpre[l] -> dpre[l-1]
+ChainOp chain_dx_op(mrgan_handle* h, int l, int a_off, int o_off, bool bias_sums) {
+    const Dense& L = h->d[l];
+    ChainOp o;
+    memset(&o, 0, sizeof o);
+    o.kind = CH_OP_GEMM; o.K = L.Np; o.N = L.Kp; o.n_valid = h->d[l - 1].N; o.W = L.W->w16; o.a_off = a_off; o.o_off = o_off;
+    o.mode = CH_DX_RELU;
+    o.out = (__bf16*)h->dpre[l - 1]; o.out_bs = (long)h->S * L.Kp; o.ldo = L.Kp;
+    o.mask = h->mask[l - 1]; o.mask_bs = (long)(h->S / 32) * h->ldm[l - 1] * 2; o.ldm = h->ldm[l - 1];
+    if (bias_sums) { o.cs = h->cs_db[l - 1]; o.ldcs = L.Kp; }
+    return o;
+}
+void chain_common(mrgan_handle* h, ChainArgs& c, int nseg) {
+    c.rows = h->B; c.nseg = nseg; c.S = h->S; c.seg0 = 0;
+    c.seed = h->cfg.seed; c.row0 = (uint32_t)(h->cfg.rank * h->B); c.st = h->state + h->cur;
+}
+double chain_flops(const mrgan_handle* h, const ChainArgs& c, bool with_head) {
+    double f = 0.0;
+    for (int l = 2; l < 5; ++l) f += 2.0 * h->B * c.nseg * h->d[l].K * h->d[l].N;     // each product appears once per direction
+    return f * (with_head ? 2.0 : 1.0);
+}
+int run_chain(mrgan_handle* h, const ChainArgs& c0, double flops, hipStream_t s) {
+    ChainArgs c = c0;
+#ifdef MRGAN_STAMPS
+    // diagnostic build: per-phase cycles of every block, printed per launch (never for timing runs)
+    static unsigned long long* stamps = nullptr;
+    if (!stamps) hipMalloc((void**)&stamps, 4096 * 8 * sizeof(unsigned long long));
+    hipMemsetAsync(stamps, 0, 4096 * 8 * sizeof(unsigned long long), s);
+    c.stamps = stamps;
+#endif
+    prof_arm(h);
+    const int r = launch_chain(c, s);
+#ifdef MRGAN_STAMPS
+    {
+        std::vector<unsigned long long> hs(4096 * 8);
+        hipStreamSynchronize(s);
+        hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nb = 0;
+        for (int b = 0; b < 4096; ++b) if (hs[b * 8]) { ++nb; for (int i = 0; i < 8; ++i) tot[i] += (double)hs[b * 8 + i]; }
+        if (nb) fprintf(stderr, "chain stamps (kcycles per block, %d blocks, %d ops): prologue %.1f | pass setup %.1f | head %.1f | tile wait %.1f | barrier %.1f | "
+                        "issue+reads+mfma %.1f | epilogue %.1f | image barrier+copy-out %.1f\n", nb, c.nops, tot[0] / nb / 1e3, tot[1] / nb / 1e3,
+                        tot[2] / nb / 1e3, tot[3] / nb / 1e3, tot[4] / nb / 1e3, tot[5] / nb / 1e3, tot[6] / nb / 1e3, tot[7] / nb / 1e3);
+    }
+#endif
+    prof_done(h, "chain_kernel", flops);
+    CHK(r);
     return 0;
 }
 
@@ -634,7 +702,7 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         CHK(gen_fwd_tail(h, h->pair_gen ? 2 : 1, 2, 2, s));               // fake rows -> slot 2 (+ the G sub-step's -> slot 3)
         h->gen_ready = h->pair_gen;
         h->pair_gen = 0;                                                  // one D sub-step per hint
-        CHK(disc_fwd_train(h, 3, false, 0, s));
+        CHK(disc_fwd_train(h, 3, false, 0, s, h->use_chain ? 2 : 5));
         HeadArgs hd;
         memset(&hd, 0, sizeof hd);
         hd.f = h->feat; hd.f_bs = (long)h->S * h->Fp; hd.ldf = h->Fp; hd.rows = B; hd.nseg = 3;
@@ -647,15 +715,34 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         hd.dpre = h->dpre[4]; hd.dpre_bs = (long)h->S * h->Fp; hd.ldd = h->Fp;
         hd.part = h->head_part; hd.part_stride = h->head_stride; hd.off_db = h->Fp * KMAX; hd.off_dbf = h->Fp * KMAX + KMAX;
         hd.loss_part = h->loss_part;
-        PROF("head_kernel", launch_head(h->bf16, hd, s));
-        for (int l = 4; l >= 1; --l)
+        if (h->use_chain) {
+            // D3 D4 D5 forward -> loss head -> dX through D5 D4 D3, one launch: the rows of a block never leave its CU
+            ChainArgs c;
+            memset(&c, 0, sizeof c);
+            chain_common(h, c, 3);
+            c.variant = CH_V_DTAIL;
+            c.a_kind = CH_A_GLOBAL; c.a = (const __bf16*)h->xin[2]; c.a_bs = (long)h->S * h->d[2].Kp; c.lda = h->d[2].Kp; c.a_cols = h->d[2].Kp;
+            c.op[0] = chain_fwd_op(h, 2, CH_BUF0, CH_BUF1, false);
+            c.op[1] = chain_fwd_op(h, 3, CH_BUF1, CH_BUF0, false);
+            c.op[2] = chain_fwd_op(h, 4, CH_BUF0, CH_BUF1, false);
+            c.op[3].kind = CH_OP_HEAD;
+            c.head = hd; c.head_f_off = CH_BUF1; c.head_o_off = CH_BUF0; c.head_scratch_off = CH_BUF0 + CH_BUF0_BYTES / 2;
+            c.op[4] = chain_dx_op(h, 4, CH_BUF0, CH_BUF1, true);
+            c.op[5] = chain_dx_op(h, 3, CH_BUF1, CH_BUF0, true);
+            c.op[6] = chain_dx_op(h, 2, CH_BUF0, CH_BUF1, true);
+            c.nops = 7;
+            CHK(run_chain(h, c, chain_flops(h, c, true), s));
+        } else {
+            PROF("head_kernel", launch_head(h->bf16, hd, s));
+        }
+        for (int l = h->use_chain ? 1 : 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 3, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_SUM, h->cs_db[l - 1], nullptr, s));
         {
             DwJob jobs[5];
             for (int l = 0; l < 5; ++l) jobs[l] = DwJob{&h->d[l], h->xin[l], h->dpre[l]};
             // the loss head's per-block weight-gradient partials are folded by extra blocks of the same launch
-            const FoldJob fold = {h->head_part, h->head_red, (long)h->head_stride, h->nblk_head, h->head_stride, h->head_groups, 0};
+            const FoldJob fold = {h->head_part, h->head_red, (long)h->head_stride, head_blocks(h), h->head_stride, h->head_groups, 0};
             CHK(dense_dw_all(h, jobs, 5, B, 3, s, &fold));
         }
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_D, ADAM_REDUCE_ONLY, true, s));
@@ -689,7 +776,19 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
     } else if (phase == MRGAN_G_FEAT) {
         if (!h->gen_ready) CHK(gen_fwd_tail(h, 1, 0, 0, s));                                    // fake rows -> slot 0
         h->gen_ready = 0;
-        CHK(disc_fwd_train(h, 2, true, h->xbase, s));
+        CHK(disc_fwd_train(h, 2, true, h->xbase, s, h->use_chain ? 2 : 5));
+        if (h->use_chain) {
+            ChainArgs c;
+            memset(&c, 0, sizeof c);
+            chain_common(h, c, 2);
+            c.variant = CH_V_GFWD;
+            c.a_kind = CH_A_GLOBAL; c.a = (const __bf16*)h->xin[2]; c.a_bs = (long)h->S * h->d[2].Kp; c.lda = h->d[2].Kp; c.a_cols = h->d[2].Kp;
+            c.op[0] = chain_fwd_op(h, 2, CH_BUF0, CH_BUF1, false);
+            c.op[1] = chain_fwd_op(h, 3, CH_BUF1, CH_BUF0, false);
+            c.op[2] = chain_fwd_op(h, 4, CH_BUF0, CH_BUF1, true);       // + the feature-matching column sums
+            c.nops = 3;
+            CHK(run_chain(h, c, chain_flops(h, c, false), s));
+        }
         if (h->sync_stats) {
             PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f, h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm, s));
         }
@@ -701,8 +800,22 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         f.ldcs = h->Fp; f.count = h->stat_count; f.grad_scale = h->fm_scale; f.feat = h->Fp; f.feat_valid = h->F;
         f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B;
         f.loss_out = h->step_out + 3; f.accum = h->accum + 3;
-        PROF("fm_kernel", launch_fm(h->bf16, f, s));
-        for (int l = 4; l >= 1; --l)
+        if (h->use_chain) {
+            // feature-matching gradient -> dX through D5 D4 D3 on the generated rows, one launch
+            ChainArgs c;
+            memset(&c, 0, sizeof c);
+            chain_common(h, c, 1);
+            c.variant = CH_V_GBWD;
+            c.a_kind = CH_A_FMGRAD; c.fm = f; c.fm_feat = (const __bf16*)h->feat; c.fm_ldf = h->Fp;
+            c.op[0] = chain_dx_op(h, 4, CH_BUF0, CH_BUF1, false);
+            c.op[1] = chain_dx_op(h, 3, CH_BUF1, CH_BUF0, false);
+            c.op[2] = chain_dx_op(h, 2, CH_BUF0, CH_BUF1, false);
+            c.nops = 3;
+            CHK(run_chain(h, c, chain_flops(h, c, false), s));
+        } else {
+            PROF("fm_kernel", launch_fm(h->bf16, f, s));
+        }
+        for (int l = h->use_chain ? 1 : 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 1, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_NONE, nullptr, nullptr, s));
         // d loss / d(generator output): noise is additive, so this is also d/d(fake x)
@@ -843,7 +956,7 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
     layout(h, h->ws, &need);
     set_gen_view(h, 0);
     h->cur = 0; h->graph_ready = false; h->graph_exec = nullptr; h->prof = false;
-    if (init_kernel_attributes() != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "hipFuncSetAttribute failed"); }
+    if (init_kernel_attributes() != 0 || chain_init_attributes() != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "hipFuncSetAttribute failed"); }
 #define CREATE_CHK(x)                                           \
     do {                                                        \
         if ((x) != hipSuccess) {                                \
@@ -1011,6 +1124,16 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
     return 0;
 }
 
+int mrgan_set_tuning(mrgan_handle* h, int knob, int value) {
+    if (!h) return fail(-1, "null handle");
+    if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_ready = false; }   // launches change
+    switch (knob) {
+        case MRGAN_TUNE_CHAIN: h->use_chain = value != 0 && h->chain_ok; h->chain_dbg = value >> 1; break;
+        default: return fail(-1, "unknown tuning knob %d", knob);
+    }
+    return 0;
+}
+
 int mrgan_pair_hint(mrgan_handle* h, int on) {
     if (!h) return fail(-1, "null handle");
     h->pair_gen = on ? 1 : 0;
@@ -1098,6 +1221,21 @@ int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t ste
 }
 
 int mrgan_debug_ablate(int bits) { g_ablate = bits; return 0; }
+
+// activation buffers of the discriminator for activation-level tests: kind 0 = xin[l] (noisy layer input), 1 = dpre[l]
+// (gradient w.r.t. the layer's pre-activation), 2 = features.  Elements are fp32 or bf16 (the handle's dtype), laid out
+// [segment][S rows][ld].
+int mrgan_debug_buffer(mrgan_handle* h, int kind, int l, void** ptr, int* rows_per_seg, int* ld, int* elem_size) {
+    if (!h || !ptr || l < 0 || l > 4) return fail(-1, "debug_buffer: bad argument");
+    switch (kind) {
+        case 0: *ptr = h->xin[l]; *ld = h->d[l].Kp; break;
+        case 1: *ptr = h->dpre[l]; *ld = h->d[l].Np; break;
+        case 2: *ptr = h->feat; *ld = h->Fp; break;
+        default: return fail(-1, "debug_buffer: unknown kind");
+    }
+    *rows_per_seg = h->S; *elem_size = h->es;
+    return 0;
+}
 
 // Kernel-level timing of one bf16 product on scratch buffers (contents irrelevant): op 0 forward (relu + noise +
 // mask), 1 input-gradient (relu mask), 2 weight-gradient.  Returns the average device time of `reps` back-to-back

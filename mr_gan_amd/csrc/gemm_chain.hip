@@ -1,0 +1,629 @@
+// Row-block chain kernel (see chain.h): consecutive dense products of one 64-row block inside one launch.
+//
+// One workgroup = 8 waves = one block of 64 rows of one segment.  The block's current activation is an LDS image
+// [K/64 k-tiles][64 rows][64 k] bf16 with the same XOR swizzle as the stand-alone forward kernel (gemm_bf16.hip), so the
+// MFMA A fragments are conflict-free ds_read_b128; the weights stream through a 2-stage ring of [256 columns][64 k] tiles
+// filled by LDS-DMA (buffer_load ... lds) from the XCD's L2.  Wave w owns output columns [32 w, 32 w + 32) of a 256-column
+// pass over all 64 rows (two 32x32 accumulators): its column sums need no cross-wave step, and the epilogue writes the
+// bf16 result straight into the LDS image that is the next product's A operand; a copy of it leaves for HBM in 16-byte
+// stores because the weight-gradient launch needs every layer's input and output gradient.
+// The ring never drains between products: the weight tile stream is one flat sequence over (product, pass, k-tile), and
+// the first tile of the next product is already in flight while the current epilogue runs.
+#include <algorithm>
+
+#include "chain.h"
+#include "gemm.h"
+
+namespace mrgan {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// byte offset of element (row, col) inside an activation image
+__device__ __forceinline__ int act_off(int row, int col) {
+    return (col >> 6) * (CH_ROWS * 128) + kc_off(row, (col & 63) >> 3) + (col & 7) * 2;
+}
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void lds_barrier() {          // LDS writes of every wave visible to every wave; VMEM left in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// wait until at most n of this wave's vector-memory operations are outstanding (they retire in issue order)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
+
+#ifdef MRGAN_STAMPS
+#define CH_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define CH_STAMP(i)
+#endif
+
+struct BCursor { int op, pass, kt; };
+
+__device__ __forceinline__ int next_gemm(const ChainArgs& a, int i) {
+    while (i < a.nops && a.op[i].kind != CH_OP_GEMM) ++i;
+    return i;
+}
+__device__ __forceinline__ bool advance(const ChainArgs& a, BCursor& c) {
+    const ChainOp& op = a.op[c.op];
+    if (++c.kt < op.K / 64) return true;
+    c.kt = 0;
+    if (++c.pass < (op.N + CH_PW - 1) / CH_PW) return true;
+    c.pass = 0;
+    c.op = next_gemm(a, c.op + 1);
+    return c.op < a.nops;
+}
+// one weight tile [256 columns][64 k] of (product, pass, k-tile) into a ring stage: 4 wave-instructions per wave
+__device__ __forceinline__ void issue_btile(const ChainArgs& a, const BCursor& c, char* stage, int wave, int lane) {
+    const ChainOp& op = a.op[c.op];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)op.W, 0, (int)((long)op.N * op.K * 2), 0x00020000);
+    const int lrow = lane >> 3, lp = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R = (wave * 4 + i) * 8 + lrow;                 // column of the pass: rows >= N of Bt read as zeros
+        const int voff = (int)(((long)(c.pass * CH_PW + R) * op.K + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
+        glds16(rs, stage + (wave * 4 + i) * 1024, voff, c.kt * 128);
+    }
+}
+
+// copy a [64 rows][256 columns] bf16 LDS image (columns col0 .. of the global tensor) out with 16-byte stores
+__device__ __forceinline__ void copy_out(const char* img, __bf16* out, int ldo, int col0, int ncols, int rows_valid, int t) {
+#pragma unroll
+    for (int u = 0; u < CH_ROWS * CH_PW / 8 / CH_THREADS; ++u) {
+        const int q = t + CH_THREADS * u, r = q >> 5, cch = q & 31;
+        if (r < rows_valid && col0 + cch * 8 < ncols)
+            *(u32x4*)(out + (long)r * ldo + col0 + cch * 8) = *(const u32x4*)(img + (cch >> 3) * (CH_ROWS * 128) + kc_off(r, cch & 7));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// loss head on the block's 64 rows (mr_gan.py:128, :146-149, :161): same arithmetic as head_kernel (aux_kernels.hip),
+// features read from the LDS image, dL/d(pre-activation of the feature layer) written as the next A image.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_head(const ChainArgs& a, char* lds, int seg, int rb, int nrb, int row_blk, int rows_valid, int t) {
+    const HeadArgs& h = a.head;
+    const char* fimg = lds + a.head_f_off;
+    float* w_lds = (float*)(lds + a.head_scratch_off);        // [feat][KMAX]
+    float* dl_lds = w_lds + h.feat * KMAX;                    // [64][KMAX]
+    float* red = dl_lds + CH_ROWS * KMAX;                     // [8 waves][16]
+    float* comb = red + 128;                                   // [feat][12]: second row-half's partial sums
+    const int lane = t & 63, wave = t >> 6;
+    const int kind = h.seg_kind[seg];
+    const int blk = seg * nrb + rb;
+
+    for (int k = t; k < h.feat; k += CH_THREADS) {
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+        if (k < h.feat_valid) { w0 = *(const f32x4*)(h.w + (long)k * h.ldw); w1 = *(const f32x4*)(h.w + (long)k * h.ldw + 4); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { if (c >= h.classes) w0[c] = 0.f; if (c + 4 >= h.classes) w1[c] = 0.f; }
+        *(f32x4*)(w_lds + k * KMAX) = w0; *(f32x4*)(w_lds + k * KMAX + 4) = w1;
+    }
+    __syncthreads();
+
+    // ---- logits: 8 lanes per row, each over an interleaved slice of the features ----
+    constexpr int LPR = CH_THREADS / CH_ROWS;
+    const int r = t / LPR, part = t % LPR;
+    float l[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) l[c] = 0.f;
+#pragma unroll 4
+    for (int kk = 0; kk < h.feat / LPR; ++kk) {
+        const int k = kk * LPR + part;
+        const float fv = (float)*(const __bf16*)(fimg + act_off(r, k));
+        const f32x4 w0 = *(const f32x4*)(w_lds + k * KMAX), w1 = *(const f32x4*)(w_lds + k * KMAX + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { l[c] = fmaf(fv, w0[c], l[c]); l[4 + c] = fmaf(fv, w1[c], l[4 + c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) l[c] += __shfl_xor(l[c], m, 64);
+    }
+    const int row = row_blk + r;
+    const bool rowvalid = r < rows_valid;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        if (c < h.classes) { l[c] += h.b[c]; mx = fmaxf(mx, l[c]); }
+    }
+    int am = 0;
+    float se = 0.f, p[KMAX];
+#pragma unroll
+    for (int c = KMAX - 1; c >= 0; --c) {
+        p[c] = (c < h.classes) ? expf(l[c] - mx) : 0.f;
+        se += p[c];
+        if (c < h.classes && l[c] == mx) am = c;          // ties -> first index (theano argmax)
+    }
+    const float lse = mx + logf(se);
+    const float inv_se = 1.0f / se;
+    float loss0 = 0.f, loss1 = 0.f, err = 0.f;
+    float dl[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) dl[c] = 0.f;
+    if (rowvalid) {
+        if (kind == HEAD_LAB) {
+            const long lo = h.labels_stream ? (long)h.st->batch * h.rows : 0;
+            const int y = h.labels[lo + row];
+            err = (am != y) ? 1.f : 0.f;
+            float ly = 0.f;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) {
+                if (c == y) ly = l[c];
+                dl[c] = (p[c] * inv_se - (c == y ? 1.f : 0.f)) * h.inv_count;
+            }
+            loss0 = lse - ly;
+        } else {
+            const float sg = sigmoid_f(lse), sp = softplus_f(lse);
+            const float k = 0.5f * h.inv_count * h.unl_weight * (kind == HEAD_UNL ? (sg - 1.0f) : sg);
+            loss1 = (kind == HEAD_UNL) ? 0.5f * (sp - lse) : 0.5f * sp;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) dl[c] = k * p[c] * inv_se;
+        }
+    }
+    if (part == 0) {
+        *(f32x4*)(dl_lds + r * KMAX) = (f32x4){dl[0], dl[1], dl[2], dl[3]};
+        *(f32x4*)(dl_lds + r * KMAX + 4) = (f32x4){dl[4], dl[5], dl[6], dl[7]};
+    } else { loss0 = 0.f; loss1 = 0.f; err = 0.f; }
+    loss0 = wave_sum(loss0); loss1 = wave_sum(loss1); err = wave_sum(err);
+    // db6 = column sums of dlogits: the lanes with part != 0 carry zeros
+    float dsum[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) dsum[c] = wave_sum(part == 0 ? dl[c] : 0.f);
+    if (lane == 0) {
+        red[wave * 16 + 0] = loss0; red[wave * 16 + 1] = loss1; red[wave * 16 + 2] = err;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) red[wave * 16 + 4 + c] = dsum[c];
+    }
+    __syncthreads();
+    float* part_row = h.part + (long)blk * h.part_stride;
+    if (t < 4 + KMAX) {
+        float s0 = 0.f;
+        for (int w = 0; w < CH_THREADS / 64; ++w) s0 += red[w * 16 + t];
+        if (t < 3) h.loss_part[blk * 4 + t] = s0;
+        else if (t == 3) h.loss_part[blk * 4 + 3] = 0.f;
+        else part_row[h.off_db + t - 4] = s0;
+    }
+
+    // ---- backward of the last dense: two threads per feature column j, 32 rows each ----
+    char* oimg = lds + a.head_o_off;
+    const int j = t & 255, half = t >> 8;
+    float dw[KMAX], dbf = 0.f;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) dw[c] = 0.f;
+    if (j < h.feat) {
+        float wj[KMAX];
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) wj[c] = w_lds[j * KMAX + c];
+#pragma unroll 4
+        for (int rr = half * 32; rr < half * 32 + 32; ++rr) {
+            const float fv = (float)*(const __bf16*)(fimg + act_off(rr, j));
+            const f32x4 d0 = *(const f32x4*)(dl_lds + rr * KMAX), d1 = *(const f32x4*)(dl_lds + rr * KMAX + 4);
+            float dfe = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dfe = fmaf(d0[c], wj[c], dfe); dfe = fmaf(d1[c], wj[4 + c], dfe);
+                dw[c] = fmaf(fv, d0[c], dw[c]); dw[4 + c] = fmaf(fv, d1[c], dw[4 + c]);
+            }
+            const float dp = (fv > 0.f) ? dfe : 0.f;
+            *(__bf16*)(oimg + act_off(rr, j)) = (__bf16)dp;
+            dbf += dp;
+        }
+        if (half == 1) {
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) comb[j * 12 + c] = dw[c];
+            comb[j * 12 + 8] = dbf;
+        }
+    }
+    __syncthreads();
+    if (half == 0 && j < h.feat) {
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) dw[c] += comb[j * 12 + c];
+        dbf += comb[j * 12 + 8];
+        *(f32x4*)(part_row + (long)j * KMAX) = (f32x4){dw[0], dw[1], dw[2], dw[3]};
+        *(f32x4*)(part_row + (long)j * KMAX + 4) = (f32x4){dw[4], dw[5], dw[6], dw[7]};
+        part_row[h.off_dbf + j] = dbf;
+    }
+    // dL/d(pre5): the next product's A image is complete (barrier above); its copy for the weight-gradient launch
+    copy_out(oimg, (__bf16*)h.dpre + (long)seg * h.dpre_bs + (long)row_blk * h.ldd, h.ldd, 0, h.feat, rows_valid, t);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// feature-matching gradient as the first A image (mr_gan.py:152-154): dL/d(pre5) = relu-mask ? 2/(J B) (m_gen - m_real) : 0
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int a_off, int rb, int row_blk, int rows_valid, int t
+#ifdef MRGAN_STAMPS
+                                             , unsigned long long (&st_acc)[8], unsigned long long& st_prev
+#endif
+) {
+    const FmArgs& f = a.fm;
+    float* gj = (float*)(lds + CH_RING + CH_STAGE_BYTES);     // the second ring stage is idle until the first k-tile step
+    float* scr = gj + CH_PW;                                  // [8][256]
+    const float* cs_real = f.cs + (long)f.npart_fake * f.ldcs;
+    // fold the per-row-block partial sums: thread <-> (4 columns, every 8th partial row), all loads of a thread in flight
+    // at once (16-byte loads), then an 8-way combine through LDS
+    {
+        const int cq = (t & 63) * 4, pg = t >> 6;
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        if (cq < f.feat) {
+            // unconditional loads from clamped rows, zero weight beyond the end: a load under a runtime condition makes
+            // hipcc branch around it and wait for each one (16 serialized round trips, ~30 k cycles measured here)
+            f32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *(const f32x4*)(f.cs + (long)min(pg + 8 * i, f.npart_fake - 1) * f.ldcs + cq);
+            for (int p = pg + 64; p < f.npart_fake; p += 8) u += *(const f32x4*)(f.cs + (long)p * f.ldcs + cq);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) u += v[i] * ((pg + 8 * i < f.npart_fake) ? 1.0f : 0.0f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *(const f32x4*)(cs_real + (long)min(pg + 8 * i, f.npart_real - 1) * f.ldcs + cq);
+            for (int p = pg + 64; p < f.npart_real; p += 8) u -= *(const f32x4*)(cs_real + (long)p * f.ldcs + cq);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) u -= v[i] * ((pg + 8 * i < f.npart_real) ? 1.0f : 0.0f);
+        }
+        *(f32x4*)(scr + pg * 256 + cq) = u;                   // scr: [8][256]
+    }
+    __syncthreads();
+    CH_STAMP(1);
+    const int c = t & 255, hf = t >> 8;
+    float sq = 0.f;
+    if (hf == 0) {
+        float sd = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) sd += scr[g * 256 + c];
+        const float diff = (c < f.feat_valid) ? sd / f.count : 0.f;
+        gj[c] = f.grad_scale * 2.0f / ((float)f.feat_valid * f.count) * diff;
+        sq = diff * diff;
+    }
+    if (rb == 0 && blockIdx.x == 0) {                         // the loss scalar, once
+        sq = wave_sum(sq);
+        __syncthreads();
+        if ((t & 63) == 0) scr[t >> 6] = sq;
+        __syncthreads();
+        if (t == 0) {
+            const float loss = (scr[0] + scr[1] + scr[2] + scr[3]) / (float)f.feat_valid;
+            if (f.loss_out) *f.loss_out = loss;
+            if (f.accum) *f.accum += loss;
+        }
+    }
+    __syncthreads();
+    CH_STAMP(2);
+    char* img = lds + a_off;
+    // thread <-> (row, 8 columns): one 16-byte chunk of the image.  relu'(pre5) comes from the stored features of the
+    // generated rows (f > 0 <=> pre5 > 0; bf16 keeps every positive value positive): one unconditional 16-byte load per chunk
+    // from a clamped row, all four in flight together.  (Decoding the lane-native mask words here instead costs 8 scattered
+    // loads per chunk: ~18 k cycles per block, measured.)
+    constexpr int NCH = CH_ROWS * CH_PW / 8 / CH_THREADS;
+    bf16x8 fv[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int q = t + CH_THREADS * u, r = q >> 5, c0 = (q & 31) * 8;
+        const bool ok = r < rows_valid && c0 < f.feat;
+        fv[u] = *(const bf16x8*)(a.fm_feat + (long)(row_blk + (ok ? r : 0)) * a.fm_ldf + (ok ? c0 : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int q = t + CH_THREADS * u, r = q >> 5, cch = q & 31, c0 = cch * 8;
+        const bool ok = r < rows_valid && c0 < f.feat;
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (__bf16)((ok && (float)fv[u][i] > 0.f) ? gj[c0 + i] : 0.f);
+        *(bf16x8*)(img + (cch >> 3) * (CH_ROWS * 128) + kc_off(r, cch & 7)) = v;
+    }
+    __syncthreads();
+    CH_STAMP(6);
+    copy_out(img, (__bf16*)f.dpre + (long)row_blk * f.ldd, f.ldd, 0, f.feat, rows_valid, t);
+    CH_STAMP(7);
+}
+
+// Shared state of the weight-tile stream of one block (all wave-uniform)
+struct Stream {
+    BCursor pc; bool more; int gtile; int first_wait;
+};
+
+// one dense product of the chain on the block's rows.  MODE is compile-time; `bias` (forward) and `mw` (the relu-mask words
+// of the output tile: read by dX, returned by forward) live in registers, loaded or produced before this call.
+template <int MODE>
+__device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op, char* lds, Stream& sm, const float bias,
+                                           uint32_t (&mw)[2][2], const int seg, const int nrb, const int rb, const int row_blk,
+                                           const int rows_valid, const uint32_t iter, const i32x4 hfrag, const int t
+#ifdef MRGAN_STAMPS
+                                           , unsigned long long (&st_acc)[8], unsigned long long& st_prev
+#endif
+) {
+    const int lane = t & 63, lc = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr bool fwd = MODE == CH_FWD_RELU;
+    const int K = op.K, N = op.N, a_off = op.a_off, o_off = op.o_off;
+    const int npass = (N + CH_PW - 1) / CH_PW, nk = K / 64;
+    const bool noisy = fwd && op.sigma > 0.f;
+    uint32_t rowhash[2] = {0u, 0u};
+    if (noisy) {
+        const uint32_t nkey = noise_key(a.seed, op.site * 256u + (uint32_t)(a.seg0 + seg), iter);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) rowhash[mi] = noise_rowhash(nkey, a.row0 + (uint32_t)(row_blk + mi * 32 + lc));
+    }
+    uint16_t* mask = op.mask ? op.mask + (long)seg * op.mask_bs : nullptr;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass >= npass) break;
+        const int col = pass * CH_PW + wave * 32 + lc;
+        const bool colin = col < N, colvalid = col < op.n_valid;
+        f32x16 acc[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        CH_STAMP(1);               // pass setup
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vm(kt == 0 ? sm.first_wait : 0);          // this wave's pieces of tile gtile have landed
+            CH_STAMP(3);                                   // wait for the weight tile
+            __builtin_amdgcn_s_barrier();                  // ... everyone's; everyone is done with tile gtile - 1 and with the A image writes
+            asm volatile("" ::: "memory");
+            CH_STAMP(4);                                   // barrier
+            if (sm.more) { issue_btile(a, sm.pc, lds + CH_RING + ((sm.gtile + 1) & 1) * CH_STAGE_BYTES, wave, lane); sm.more = advance(a, sm.pc); }
+            const char* As = lds + a_off + kt * (CH_ROWS * 128);
+            const char* Bs = lds + CH_RING + (sm.gtile & 1) * CH_STAGE_BYTES;
+            ++sm.gtile;
+            // fragments of two k-steps per batch: their LDS latency is paid once per batch (the other wave of the SIMD
+            // covers the rest); a deeper batch costs registers the epilogue needs
+#pragma unroll
+            for (int kg = 0; kg < 4; kg += 2) {
+                bf16x8 fa[2][2], fb[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    fa[ks][0] = *(const bf16x8*)(As + kc_off(lc, (kg + ks) * 2 + lh));
+                    fa[ks][1] = *(const bf16x8*)(As + kc_off(32 + lc, (kg + ks) * 2 + lh));
+                    fb[ks] = *(const bf16x8*)(Bs + kc_off(wave * 32 + lc, (kg + ks) * 2 + lh));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0], fb[ks], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][1], fb[ks], acc[1], 0, 0, 0);
+                }
+            }
+            CH_STAMP(5);                                   // tile issue + fragment reads + MFMAs
+        }
+
+        // ---- epilogue: bias / relu / mask / noise, bf16 into the output image, column sums ----
+        char* oimg = lds + o_off;
+        const int cip = wave * 32 + lc;                    // column inside the pass = column of the output image
+        // element (row, cip) of the image sits at obase[sel(r)] + a compile-time offset: the swizzle term (row>>1)&7 of
+        // row = 32 mi + (r&3) + 8 (r>>2) + 4 lh is  ((r>>1)&1) | lh<<1 | ((r>>2)&1)<<2, i.e. a lane part and 4 register cases
+        int obase[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            obase[i] = (cip >> 6) * (CH_ROWS * 128) + lh * 512 + (((((cip & 63) >> 3) ^ (lh << 1)) ^ ((i & 1) | ((i >> 1) << 2))) << 4) + (cip & 7) * 2;
+        const float sig = (noisy && colvalid) ? op.sigma * NOISE_SCALE : 0.f;
+        float s1 = 0.f;
+        auto ostore = [&](int mi, int r, float o) {
+            *(__bf16*)(oimg + obase[((r >> 1) & 1) | (((r >> 2) & 1) << 1)] + (mi * 32 + (r & 3) + 8 * (r >> 2)) * 128) = (__bf16)o;
+        };
+        if constexpr (fwd) {
+            const float bv = colvalid ? bias : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                i32x16 nzs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (noisy) nzs = noise_block(rowhash[mi], (uint32_t)col >> 5, lane, hfrag);
+                uint32_t mbits = 0u;
+                // Rows >= rows_valid of a ragged block carry relu(bias) + noise instead of zeros.  That is harmless: every
+                // product is row-local, copy_out never stores those rows, the head gives them zero dlogits -- only a
+                // column sum must leave them out (below).  Masking them here would cost a compare per element, whose 32
+                // lane masks hipcc keeps in SGPR pairs for the whole kernel (250 spilled SGPRs, ~2 k cycles per pass).
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaxf(acc[mi][r] + bv, 0.f);
+                    mbits |= min(__builtin_bit_cast(uint32_t, v), 1u) << r;
+                    s1 += v;
+                    acc[mi][r] = v;
+                    ostore(mi, r, fmaf(sig, (float)nzs[r], v));       // sig = 0 without noise
+                }
+                mw[pass][mi] = mbits;
+                if (mask && colin && row_blk + mi * 32 < a.rows)
+                    mask[((long)((row_blk + mi * 32) >> 5) * op.ldm + col) * 2 + lh] = (uint16_t)mbits;
+            }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // rows >= rows_valid and padding columns arrive as exact zeros (zero A rows / zero weights).
+                    // (a select, not a bit-AND on the accumulator element: hipcc 7.2 mis-folds that form)
+                    const float av = acc[mi][r];
+                    const float v = ((mw[pass][mi] >> r) & 1u) ? av : 0.f;
+                    s1 += v;
+                    ostore(mi, r, v);
+                }
+            }
+        }
+        if (op.cs) {
+            if (fwd && rows_valid < CH_ROWS) {                 // ragged block: the column sum again, without the padding rows
+                s1 = 0.f;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s1 += (mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < rows_valid) ? acc[mi][r] : 0.f;
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            if (lh == 0 && col < op.ldcs) op.cs[((long)seg * nrb + rb) * op.ldcs + col] = s1;
+        }
+        CH_STAMP(6);                                       // epilogue math + image writes
+        lds_barrier();                                     // the output image is complete
+        if (op.out)
+            copy_out(oimg, op.out + (long)seg * op.out_bs + (long)row_blk * op.ldo, op.ldo, pass * CH_PW, N, rows_valid, t);
+        // The copy-out stores are the youngest VMEM ops of this wave and may stay in flight over the next tile wait --
+        // but only when every wave really issued all of them (a full block and a full pass; a wave whose lanes are
+        // all predicated off may skip the instruction, and an over-counted wait would not cover the weight tile).
+        sm.first_wait = (op.out && rows_valid == CH_ROWS && N - pass * CH_PW >= CH_PW) ? CH_ROWS * CH_PW / 8 / CH_THREADS : 0;
+        CH_STAMP(7);                                       // image barrier + copy-out issue
+    }
+}
+
+// relu-mask words of a dX product's output tile, from HBM (written by an earlier launch)
+__device__ __forceinline__ void load_mask_words(const ChainArgs& a, const ChainOp& op, uint32_t (&mw)[2][2], int seg, int row_blk, int wave, int lc, int lh) {
+    const uint16_t* mask = op.mask + (long)seg * op.mask_bs;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int col = pass * CH_PW + wave * 32 + lc;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            // branch-free (see chain_fmgrad): clamped address, result zeroed when out of range
+            const bool ok = col < op.N && row_blk + mi * 32 < a.rows;
+            const uint32_t w = mask[((long)((ok ? row_blk + mi * 32 : 0) >> 5) * op.ldm + (ok ? col : 0)) * 2 + lh];
+            mw[pass][mi] = ok ? w : 0u;
+        }
+    }
+}
+
+#ifdef MRGAN_STAMPS
+#define CH_ST_ARGS , st_acc, st_prev
+#else
+#define CH_ST_ARGS
+#endif
+
+// VARIANT: the three chains of one training step (chain.h).  The op list is fixed per variant, so the loop over products is
+// unrolled at compile time: epilogue inputs are loaded once at the top (before the weight stream loads the memory
+// pipeline), relu masks of products whose forward ran in this launch never leave registers, and no per-op descriptor
+// reload sits between two products.
+template <int VARIANT>
+__global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, lc = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nrb = (a.rows + CH_ROWS - 1) / CH_ROWS;
+    const int seg = blockIdx.x / nrb, rb = blockIdx.x - seg * nrb;
+    const int row_blk = rb * CH_ROWS, rows_valid = min(CH_ROWS, a.rows - row_blk);
+
+#ifdef MRGAN_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#endif
+    // Keras iteration of this sub-step (noise key): loaded before the weight stream starts and pinned in an SGPR -- sunk to its
+    // first use, the load would sit behind a vmcnt(0) that also drains the weight-tile DMA
+    uint32_t iter = a.st ? __builtin_amdgcn_readfirstlane((int)a.st->iter) : 0u;
+    asm volatile("" : "+s"(iter));
+    // ---- epilogue inputs of every product: biases (forward) and the relu masks that come from HBM ----
+    const int col0 = wave * 32 + lc;
+    float bias[3] = {0.f, 0.f, 0.f};
+    uint32_t mwA[2][2] = {{0u, 0u}, {0u, 0u}}, mwB[2][2] = {{0u, 0u}, {0u, 0u}}, mwC[2][2] = {{0u, 0u}, {0u, 0u}};
+    if constexpr (VARIANT != CH_V_GBWD) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const float bv = a.op[i].bias[min(col0, a.op[i].n_valid - 1)]; bias[i] = col0 < a.op[i].n_valid ? bv : 0.f; }
+    }
+    if constexpr (VARIANT == CH_V_DTAIL) load_mask_words(a, a.op[6], mwC, seg, row_blk, wave, lc, lh);      // dX through D3 needs D2's mask
+    if constexpr (VARIANT == CH_V_GBWD) {
+        load_mask_words(a, a.op[0], mwA, seg, row_blk, wave, lc, lh);
+        load_mask_words(a, a.op[1], mwB, seg, row_blk, wave, lc, lh);
+        load_mask_words(a, a.op[2], mwC, seg, row_blk, wave, lc, lh);
+    }
+
+    // ---- the weight-tile stream ----
+    Stream sm;
+    sm.pc = BCursor{next_gemm(a, 0), 0, 0};
+    sm.more = sm.pc.op < a.nops; sm.gtile = 0; sm.first_wait = 0;
+    if (sm.more) { issue_btile(a, sm.pc, lds + CH_RING, wave, lane); sm.more = advance(a, sm.pc); }
+
+    // ---- first A image ----
+    const int a0_off = a.op[0].a_off;
+    if constexpr (VARIANT != CH_V_GBWD) {
+        const __bf16* src = a.a + (long)seg * a.a_bs;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)((long)a.rows * a.lda * 2), 0x00020000);
+        const int lrow = lane >> 3, lp = lane & 7, nkt = a.a_cols / 64;
+        // 8 pieces of [8 rows][128 B] per k-tile, spread over the waves: rows >= a.rows arrive as zeros
+        for (int pce = wave; pce < nkt * 8; pce += CH_THREADS / 64) {
+            const int kt = pce >> 3, R = (pce & 7) * 8 + lrow;
+            const int voff = (int)(((long)(row_blk + R) * a.lda + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
+            glds16(rsA, lds + a0_off + kt * (CH_ROWS * 128) + (pce & 7) * 1024, voff, kt * 128);
+        }
+    } else {
+        chain_fmgrad(a, lds, a0_off, rb, row_blk, rows_valid, t CH_ST_ARGS);
+    }
+    CH_STAMP(0);                   // prologue (epilogue inputs, first tile issue, A image)
+
+    const i32x4 hfrag = hadamard_frag(lane);
+    // the op index goes through an opaque asm so that the descriptor's scalar loads happen at the product's start: hoisted to
+    // the top of the kernel (what hipcc does with a constant index) seven descriptors overflow the SGPR file and every
+    // pass pays ~2 k cycles of spill traffic
+    auto opq = [](int i) { asm volatile("" : "+s"(i)); return i; };
+    // ... and the descriptor is copied as a whole (wide scalar loads, one wait) instead of field by field at the points of use
+#define CH_GEMM(MODE, I, BIAS, MW) do { const ChainOp op_ = a.op[opq(I)]; chain_gemm<MODE>(a, op_, lds, sm, BIAS, MW, seg, nrb, rb, row_blk, rows_valid, iter, hfrag, t CH_ST_ARGS); } while (0)
+    if constexpr (VARIANT == CH_V_DTAIL) {
+        // D3 D4 D5 forward: the masks of D3 / D4 stay in registers for the way back
+        uint32_t mw4[2][2];
+        CH_GEMM(CH_FWD_RELU, 0, bias[0], mwB);
+        CH_GEMM(CH_FWD_RELU, 1, bias[1], mwA);
+        CH_GEMM(CH_FWD_RELU, 2, bias[2], mw4);
+        wait_vm(0);                // (the pending weight tile is simply waited for: the head is long)
+        lds_barrier();
+        CH_STAMP(1);
+        chain_head(a, lds, seg, rb, nrb, row_blk, rows_valid, t);
+        CH_STAMP(2);               // loss head
+        sm.first_wait = 0;
+        CH_GEMM(CH_DX_RELU, 4, 0.f, mwA);       // dX through D5 * relu'(D4)
+        CH_GEMM(CH_DX_RELU, 5, 0.f, mwB);       // dX through D4 * relu'(D3)
+        CH_GEMM(CH_DX_RELU, 6, 0.f, mwC);       // dX through D3 * relu'(D2)
+    } else if constexpr (VARIANT == CH_V_GFWD) {
+        uint32_t mwx[2][2];
+        CH_GEMM(CH_FWD_RELU, 0, bias[0], mwx);
+        CH_GEMM(CH_FWD_RELU, 1, bias[1], mwx);
+        CH_GEMM(CH_FWD_RELU, 2, bias[2], mwx);
+    } else {
+        CH_GEMM(CH_DX_RELU, 0, 0.f, mwA);
+        CH_GEMM(CH_DX_RELU, 1, 0.f, mwB);
+        CH_GEMM(CH_DX_RELU, 2, 0.f, mwC);
+    }
+#undef CH_GEMM
+#ifdef MRGAN_STAMPS
+    if (a.stamps && t == 0)
+        for (int i = 0; i < 8; ++i) a.stamps[(long)blockIdx.x * 8 + i] = st_acc[i];
+#endif
+}
+
+}  // namespace
+
+int chain_init_attributes() {
+    hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_DTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GFWD>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GBWD>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES);
+    return e == hipSuccess ? 0 : -2;
+}
+
+int launch_chain(const ChainArgs& a, hipStream_t s) {
+    // the three fixed op lists (chain.h)
+    static const int want[3][CH_MAX_OPS] = {{CH_OP_GEMM, CH_OP_GEMM, CH_OP_GEMM, CH_OP_HEAD, CH_OP_GEMM, CH_OP_GEMM, CH_OP_GEMM, -1},
+                                            {CH_OP_GEMM, CH_OP_GEMM, CH_OP_GEMM, -1, -1, -1, -1, -1},
+                                            {CH_OP_GEMM, CH_OP_GEMM, CH_OP_GEMM, -1, -1, -1, -1, -1}};
+    static const int nops[3] = {7, 3, 3};
+    if (a.variant < 0 || a.variant > 2 || a.nops != nops[a.variant]) return -3;
+    for (int i = 0; i < a.nops; ++i) {
+        const ChainOp& op = a.op[i];
+        if (op.kind != want[a.variant][i]) return -3;
+        if (op.kind != CH_OP_GEMM) continue;
+        const bool fwd = a.variant == CH_V_GFWD || (a.variant == CH_V_DTAIL && i < 3);
+        if (op.mode != (fwd ? CH_FWD_RELU : CH_DX_RELU)) return -3;
+        if ((op.K % 64) || (op.N % 64) || op.K > CH_KMAX || op.K < 64 || op.N > 2 * CH_PW || !op.W) return -3;
+        if (fwd && op.N > CH_PW) return -3;                    // a forward output is the next product's A image
+        if (!fwd && !op.mask) return -3;
+        if (fwd && !op.bias) return -3;
+        if ((long)op.N * op.K * 2 >= (1L << 31)) return -3;
+    }
+    if (a.variant != CH_V_GBWD && ((a.a_cols % 64) || a.a_cols > CH_KMAX || a.a_cols != a.op[0].K || (long)a.rows * a.lda * 2 >= (1L << 31))) return -3;
+    const int nrb = (a.rows + CH_ROWS - 1) / CH_ROWS;
+    const dim3 grid(nrb * a.nseg), block(CH_THREADS);
+    if (a.variant == CH_V_DTAIL) MRGAN_LAUNCH(chain_kernel<CH_V_DTAIL>, grid, block, CH_LDS_BYTES, s, a);
+    else if (a.variant == CH_V_GFWD) MRGAN_LAUNCH(chain_kernel<CH_V_GFWD>, grid, block, CH_LDS_BYTES, s, a);
+    else MRGAN_LAUNCH(chain_kernel<CH_V_GBWD>, grid, block, CH_LDS_BYTES, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace mrgan

@@ -18,6 +18,7 @@ NET_G, NET_D = 0, 1
 FLAG_SYNC_STATS, FLAG_FLAT_GRADS, FLAG_GRAPH = 1, 2, 4
 D_GEN, D_MAIN, D_ADAM = 0, 1, 2
 G_GEN, G_FEAT, G_BWD, G_TAIL, G_ADAM = 0, 1, 2, 3, 4
+TUNE_CHAIN = 0
 REGION_BN_STATS, REGION_FM_MOMENTS, REGION_BN_BWD, REGION_GRAD_D, REGION_GRAD_G, REGION_WORKSPACE = range(6)
 
 EXPORTS = [
@@ -25,7 +26,7 @@ EXPORTS = [
     "mrgan_num_tensors", "mrgan_tensor_shape", "mrgan_set_weights", "mrgan_get_weights", "mrgan_get_slot",
     "mrgan_set_slot", "mrgan_get_iterations", "mrgan_set_iterations", "mrgan_disc_step", "mrgan_gen_step",
     "mrgan_train_pair", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
-    "mrgan_pair_hint", "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time",
+    "mrgan_pair_hint", "mrgan_set_tuning", "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time", "mrgan_debug_buffer",
 ]
 PROF_NAME_LEN = 96
 
@@ -240,6 +241,10 @@ class Engine(object):
     def train_pair(self, dargs, gargs):
         _check(self.lib.mrgan_train_pair(self.handle, C.byref(dargs), C.byref(gargs), _stream()))
 
+    def set_tuning(self, knob, value):
+        """launch-structure knobs (TUNE_*): results stay within rounding"""
+        _check(self.lib.mrgan_set_tuning(self.handle, int(knob), int(value)))
+
     def pair_hint(self, on=True):
         """the next disc_step is followed by a gen_step with device-drawn z: share the generator pass (no-op with synced statistics)"""
         _check(self.lib.mrgan_pair_hint(self.handle, 1 if on else 0))
@@ -285,6 +290,16 @@ class Engine(object):
         _check(self.lib.mrgan_region(self.handle, which, C.byref(p), C.byref(n)))
         off = p.value - self.workspace.data_ptr()
         return self.workspace[off:off + n.value].view(torch.float32)
+
+    def debug_buffer(self, kind, l, nseg=3):
+        """activation buffer (0 xin[l], 1 dpre[l], 2 features) as a float32 tensor [nseg, S, ld] (a copy)"""
+        p, rows, ld, es = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        _check(self.lib.mrgan_debug_buffer(self.handle, kind, l, C.byref(p), C.byref(rows), C.byref(ld), C.byref(es)))
+        off = p.value - self.workspace.data_ptr()
+        n = nseg * rows.value * ld.value * es.value
+        raw = self.workspace[off:off + n]
+        t = raw.view(torch.bfloat16 if es.value == 2 else torch.float32)
+        return t.reshape(nseg, rows.value, ld.value).float().clone()
 
     def debug_noise(self, site, seg, step, rows, cols, row0=0):
         out = torch.empty((rows, cols), dtype=torch.float32, device=self.device)

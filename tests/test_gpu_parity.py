@@ -313,6 +313,37 @@ def test_bf16_gradients_match_bf16_mirror(D, B):
     _grad_parity(D, B, 1, 'bf16', tol=3e-3, tol_loss=5e-4)
 
 
+@pytest.mark.parametrize("D,B", [(400, 256), (96, 50), (512, 1024)])
+def test_chain_launches_equal_per_layer_launches(D, B):
+    """The 256-wide tail D3..D5 + loss head (+ its dX chain) as row-block chain launches (gemm_chain.hip) against the same
+    products launched layer by layer: identical MFMA accumulation order and epilogue arithmetic, so the gradients agree to
+    fp32 summation order of the column / head partial sums (B = 50: a ragged, partly empty row block)."""
+    from mr_gan_amd import engine as E
+    case = Case(D=D, B=B, steps=1, device_z=True)
+    res = []
+    for chain in (1, 0):
+        eng = _engine(D, B, 1, flags=E.FLAG_FLAT_GRADS)
+        eng.set_tuning(E.TUNE_CHAIN, chain)
+        _load(eng, case)
+        da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]))
+        eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
+        gd = eng.get_slot(E.NET_D, 2)
+        out = eng.disc_step(da, E.D_ADAM, E.D_ADAM)
+        ga = E.Engine.gen_args(_t(case.x_unl2[0]))
+        eng.gen_step(ga, E.G_GEN, E.G_TAIL, want_outputs=False)
+        gg = eng.get_slot(E.NET_G, 2)
+        lg = eng.gen_step(ga, E.G_ADAM, E.G_ADAM)
+        res.append((gd, out, gg, lg))
+        eng.close()
+    (gd1, out1, gg1, lg1), (gd0, out0, gg0, lg0) = res
+    np.testing.assert_allclose(out1, out0, rtol=1e-6, atol=1e-7)
+    assert abs(lg1 - lg0) <= 1e-6 * abs(lg0)
+    for i, (a, b) in enumerate(zip(gd1, gd0)):
+        assert rel_err(a, b) < 2e-6, ("dD", i, rel_err(a, b))
+    for i, (a, b) in enumerate(zip(gg1, gg0)):
+        assert rel_err(a, b) < 2e-5, ("dG", i, rel_err(a, b))
+
+
 def test_wide_stack_bf16_matches_bf16_mirror():
     """BASELINE configs[4] geometry at one rank's share: hidden 4096 x 5 (generator 4096 x 2), D = 512, B = 8192 / 8 = 1024.
     The layer widths are literals in the reference (mr_gan.py:111-128); mrgan_config generalises them."""
