@@ -19,10 +19,9 @@ struct StageSeg {
     uint32_t iter_off;                              // noise key uses DevState::iter + iter_off (z of a later sub-step)
 };
 struct StageArgs {
-    StageSeg s[4]; int nseg;
+    StageSeg s[5]; int nseg;
     uint64_t seed; uint32_t row0;
-    const DevState* cur; DevState* next; int advance_batch;
-    float lr, b1, b2;
+    const DevState* cur;
 };
 int launch_stage(int bf16, const StageArgs& a, hipStream_t s);
 
@@ -101,6 +100,9 @@ struct AdamArgs {
     // metrics finish (block 0): loss partials of this sub-step -> step_out[0..2] and epoch accumulators
     const float* loss_part; int nloss_part; float inv_rows; float* step_out; float* accum;
     float* flat_tail;                                  // 4 floats after the flat gradients (travel with the all-reduce)
+    // The updating launch is the last kernel of a sub-step: it publishes the next sub-step's DevState slot
+    // (iterations + 1, batch counter + advance_batch, lr_t of the new iteration).  Null for ADAM_REDUCE_ONLY.
+    DevState* next; int advance_batch; float lr;
 };
 int launch_adam(const AdamArgs& a, hipStream_t s);
 

@@ -34,8 +34,7 @@ template <> __device__ __forceinline__ void store8<__bf16>(__bf16* p, const floa
 
 // =========================================================================================
 // stage: gather rows (optionally by index) of the resident fp32 matrix, add GaussianNoise(sigma)
-// (mr_gan.py:118), convert to T, zero the padding columns.  Also draws z when asked to, and --
-// being the first kernel of every sub-step -- publishes the next DevState slot.
+// (mr_gan.py:118), convert to T, zero the padding columns.  Also draws z when asked to.
 // wave <-> 32 rows x 128 columns.  The noise generator (common.h) delivers a 32x32 block in the MFMA accumulator
 // layout (lane = column, 16 rows in registers); the integer sums (|s| <= 4064) go through a per-wave int16 LDS image so
 // that global loads and stores move 8 consecutive columns per lane (2 x 16 B in, 16 B out).
@@ -44,15 +43,6 @@ template <typename T>
 __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
     __shared__ __attribute__((aligned(16))) short nlds[4][32][128 + 8];          // +8: rows 272 B apart (bank spread for the 2-byte writes)
     const DevState st = *a.cur;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && a.next) {
-        DevState nx;
-        nx.iter = st.iter + 1;
-        nx.batch = st.batch + (uint32_t)a.advance_batch;
-        const double t = (double)nx.iter + 1.0;
-        nx.lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, t)) / (1.0 - pow((double)a.b1, t)));
-        nx.pad = 0;
-        *a.next = nx;
-    }
     const StageSeg& sg = a.s[blockIdx.z];
     const int lane = threadIdx.x & 63, lc = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -571,7 +561,17 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         }
     }
     }
-    // ---- metrics: the extra last block folds this sub-step's loss partials ----
+    // ---- the extra last block: the next sub-step's DevState, and this sub-step's loss partials ----
+    if (blockIdx.x == a.ntiles && t == 0 && a.next && a.mode != ADAM_REDUCE_ONLY) {
+        const DevState st = *a.st;
+        DevState nx;
+        nx.iter = st.iter + 1;
+        nx.batch = st.batch + (uint32_t)a.advance_batch;
+        const double tt = (double)nx.iter + 1.0;
+        nx.lr_t = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, tt)) / (1.0 - pow((double)a.b1, tt)));
+        nx.pad = 0;
+        *a.next = nx;
+    }
     if (blockIdx.x == a.ntiles && a.step_out) {
         __shared__ float ms[3][256];
         float s[3] = {0.f, 0.f, 0.f};

@@ -102,6 +102,7 @@ struct mrgan_handle {
     void *zbuf_all, *h1_all, *hbn_all, *h2_all;   // [2][S] rows: segment 1 = the G sub-step's batch when a pair runs its two
                                                   // generator forwards as one (pair_gen)
     int pair_gen, gen_ready;             // train_pair: D_GEN also ran the G sub-step's generator forward
+    const mrgan_gen_args* pair_g; int real_staged;   // train_pair: ... and staged the G sub-step's real rows
     int xbase;                           // first xin[0] slot of the current G sub-step (0, or 3 after a paired forward)
     void* xin[5]; void* feat; uint16_t* mask[5]; int ldm[5];
     void* dpre[5];
@@ -521,9 +522,10 @@ void* rowptr(mrgan_handle* h, void* base, long row, int ld) { return (char*)base
 // per-block partial rows the loss head wrote in this sub-step
 int head_blocks(const mrgan_handle* h) { return 3 * ceil_div(h->B, h->use_chain ? CH_ROWS : HEAD_ROWS); }
 
-int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t s) {
+int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t s, int advance_batch = 0) {
     AdamArgs a;
     memset(&a, 0, sizeof a);
+    if (mode != ADAM_REDUCE_ONLY) { a.next = h->state + (h->cur ^ 1); a.advance_batch = advance_batch; a.lr = h->cfg.lr; }
     a.tiles = net == MRGAN_NET_D ? h->tiles_d_dev : h->tiles_g_dev;
     a.ntiles = net == MRGAN_NET_D ? h->ntiles_d : h->ntiles_g;
     a.mode = mode; a.b1 = h->cfg.beta1; a.b2 = h->cfg.beta2; a.eps = h->cfg.adam_eps;
@@ -657,7 +659,7 @@ int run_chain(mrgan_handle* h, const ChainArgs& c0, double flops, hipStream_t s)
     return 0;
 }
 
-int stage_common(StageArgs& st, mrgan_handle* h, const float* z, int stream_mode, int advance_batch, int slot, bool paired_z = false) {
+int stage_common(StageArgs& st, mrgan_handle* h, const float* z, int stream_mode, int slot, bool paired_z = false) {
     if (slot >= 0) {
         StageSeg& zs = st.s[slot];
         memset(&zs, 0, sizeof zs);
@@ -672,8 +674,7 @@ int stage_common(StageArgs& st, mrgan_handle* h, const float* z, int stream_mode
         }
     }
     st.seed = h->cfg.seed; st.row0 = (uint32_t)(h->cfg.rank * h->B);
-    st.cur = h->state + h->cur; st.next = h->state + (h->cur ^ 1); st.advance_batch = advance_batch;
-    st.lr = h->cfg.lr; st.b1 = h->cfg.beta1; st.b2 = h->cfg.beta2;
+    st.cur = h->state + h->cur;
     return 0;
 }
 void data_seg(StageSeg& sg, mrgan_handle* h, const float* x, const int32_t* idx, long ld, int slot, uint32_t seg_id, int stream_mode) {
@@ -695,7 +696,17 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         data_seg(st.s[0], h, a->x_lab_dev, a->idx_lab_dev, a->ld_x_lab, 0, 0, a->stream_mode);
         data_seg(st.s[1], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, 1, 1, a->stream_mode);
         set_gen_view(h, 0);
-        stage_common(st, h, a->z_dev, a->stream_mode, 0, 2, h->pair_gen != 0);
+        stage_common(st, h, a->z_dev, a->stream_mode, 2, h->pair_gen != 0);
+        h->real_staged = 0;
+        if (h->pair_gen && h->pair_g) {
+            // mrgan_train_pair: the G sub-step's real rows (its x_unl batch, drawn at iteration + 1) ride in this launch too
+            const mrgan_gen_args* g = h->pair_g;
+            StageSeg& rs = st.s[st.nseg];
+            data_seg(rs, h, g->x_unl_dev, g->idx_unl_dev, g->ld_x_unl, 4, 1, g->stream_mode);
+            rs.iter_off = 1;
+            st.nseg += 1;
+            h->real_staged = 1;
+        }
         PROF("stage_kernel", launch_stage(h->bf16, st, s));
         CHK(gen_fwd_head(h, h->pair_gen ? 2 : 1, s));
     } else if (phase == MRGAN_D_MAIN) {
@@ -768,10 +779,14 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         h->gen_ready = ready ? 1 : 0;
         h->xbase = ready ? 3 : 0;
         set_gen_view(h, ready ? 1 : 0);
-        data_seg(st.s[0], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, h->xbase + 1, 1, a->stream_mode);   // real rows
-        st.nseg = 1;
-        stage_common(st, h, a->z_dev, a->stream_mode, a->stream_mode ? 1 : 0, ready ? -1 : 1);
-        PROF("stage_kernel", launch_stage(h->bf16, st, s));
+        const bool staged = ready && h->real_staged;           // the D sub-step's stage launch already placed the real rows in slot 4
+        h->real_staged = 0;
+        if (!staged) {
+            data_seg(st.s[0], h, a->x_unl_dev, a->idx_unl_dev, a->ld_x_unl, h->xbase + 1, 1, a->stream_mode);   // real rows
+            st.nseg = 1;
+            stage_common(st, h, a->z_dev, a->stream_mode, ready ? -1 : 1);
+            PROF("stage_kernel", launch_stage(h->bf16, st, s));
+        }
         if (!ready) CHK(gen_fwd_head(h, 1, s));
     } else if (phase == MRGAN_G_FEAT) {
         if (!h->gen_ready) CHK(gen_fwd_tail(h, 1, 0, 0, s));                                    // fake rows -> slot 0
@@ -843,7 +858,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         }
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_G, ADAM_REDUCE_ONLY, false, s));
     } else if (phase == MRGAN_G_ADAM) {
-        CHK(run_adam(h, MRGAN_NET_G, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, false, s));
+        CHK(run_adam(h, MRGAN_NET_G, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, false, s, a->stream_mode ? 1 : 0));
         h->cur ^= 1;
     }
     return 0;
@@ -871,7 +886,7 @@ int eval_rows(mrgan_handle* h, const float* x, const int32_t* idx, long ld, cons
         StageSeg& sg = st.s[0];
         sg.src = idx ? x : x + r0 * ld; sg.idx = idx ? idx + r0 : nullptr; sg.ld = ld; sg.rows = rows;
         sg.cols = h->cfg.d_in; sg.cols_pad = h->Dp; sg.out = h->xin[0]; sg.ldo = h->Dp;
-        st.nseg = 1; st.seed = h->cfg.seed; st.cur = h->state + h->cur; st.next = nullptr;
+        st.nseg = 1; st.seed = h->cfg.seed; st.cur = h->state + h->cur;
         PROF("stage_kernel", launch_stage(h->bf16, st, s));
         for (int l = 0; l < 5; ++l) {
             // one "segment" of `rows` contiguous rows: batch stride is irrelevant with nb = 1
@@ -956,6 +971,7 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
     layout(h, h->ws, &need);
     set_gen_view(h, 0);
     h->cur = 0; h->graph_ready = false; h->graph_exec = nullptr; h->prof = false;
+    h->pair_gen = h->gen_ready = 0; h->pair_g = nullptr; h->real_staged = 0;
     if (init_kernel_attributes() != 0 || chain_init_attributes() != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "hipFuncSetAttribute failed"); }
 #define CREATE_CHK(x)                                           \
     do {                                                        \
@@ -1094,8 +1110,9 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
     static const int pair_env = []() { const char* e = getenv("MRGAN_PAIR_GEN"); return e ? atoi(e) : 1; }();
     auto both = [&]() {
         h->pair_gen = (pair_env && !h->sync_stats && !g->z_dev) ? 1 : 0;
+        h->pair_g = h->pair_gen ? g : nullptr;
         int rr = mrgan_disc_step(h, d, 0, -1, nullptr, stream);
-        h->pair_gen = 0;
+        h->pair_gen = 0; h->pair_g = nullptr;
         if (!rr) rr = mrgan_gen_step(h, g, 0, -1, nullptr, stream);
         h->gen_ready = 0;
         return rr;
