@@ -5,9 +5,10 @@ One step = one discriminator sub-step (B labeled + B unlabeled + B generated row
 sub-step (B generated + B unlabeled rows), Adam included (mr_gan.py:204-213).  Workload = BASELINE
 config 2: synthetic N=65536 x D=512, K=6, batch 4096, bf16 MFMA with fp32 accumulate/master weights.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); per-GPU batch stays
-4096 (weak scaling) and `value` counts batch-4096 steps summed over ranks.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--global-batch G]
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Default: per-GPU batch stays
+4096 (weak scaling) and `value` counts batch-4096 steps summed over ranks.  --global-batch G: every rank takes G / N rows
+of each stream (strong scaling at a fixed global batch) and `value` counts global-batch steps.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live: per-launch hipEvent pairs recorded by the
 library on the launch stream over a separate profiled pass (never the timed region's numbers re-used),
@@ -27,6 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.29 TB/s measured by a float4 copy), same guide
 
 
 def algorithmic_flops(B, D, g_hidden=(500, 500), d_hidden=(1000, 500, 250, 250, 250), K=6, nz=100):
@@ -66,36 +68,104 @@ def build_problem(args, rank):
     return X, y, xl, yl
 
 
-def cpu_baseline(args, X, xl, yl, budget_s=15.0):
-    """The CPU oracle (numpy fp32, BLAS threads = all host cores) on the same workload, bounded sample."""
+def cpu_baseline(args, X, xl, yl, budget_s=12.0):
+    """The CPU path timed beside the GPU one on a bounded sample of the same workload.  The reference's Theano/Keras path
+    cannot run, so both variants are ports (`kind`): (i) the numpy oracle in fp32 with its noise drawn inside
+    the loop, as mr_gan.py:206 does; (ii) a PyTorch-CPU fp32 module of the same step with torch.set_num_threads(all cores)
+    and pre-generated noise.  `value` is the faster of the two."""
     from oracle import mrgan_oracle as O
     rng = np.random.default_rng(0)
     B, D = args.batch, args.d
-    g, d = O.init_params(D, seed=1, dtype=np.float32)
-    orc = O.MRGANOracle(g, d)
     dims = (D,) + O.D_HIDDEN
 
-    def noise():
-        return [rng.standard_normal((B, dims[l]), dtype=np.float32) for l in range(5)]
+    def run_numpy():
+        g, d = O.init_params(D, seed=1, dtype=np.float32)
+        orc = O.MRGANOracle(g, d)
+        noise = lambda: [rng.standard_normal((B, dims[l]), dtype=np.float32) for l in range(5)]
 
-    def one_step():
-        il = rng.integers(0, xl.shape[0], B)
-        iu = rng.integers(0, X.shape[0], B)
-        z = rng.standard_normal((B, O.NOISE_SIZE), dtype=np.float32)
-        orc.disc_step(xl[il], yl[il], X[iu], z, noise(), noise(), noise())
-        z = rng.standard_normal((B, O.NOISE_SIZE), dtype=np.float32)
-        orc.gen_step(X[iu], z, noise(), noise())
-    one_step()                                                        # warm-up (BLAS thread pool, page-in)
-    n, t0 = 0, time.time()
-    while True:
-        one_step()
-        n += 1
-        if time.time() - t0 > budget_s or n >= 64:
-            break
-    dt = time.time() - t0
-    return dict(value=n / dt, unit="steps/s", cores=os.cpu_count(), kind="port",
-                sample="%d steps of the same workload (B=%d, D=%d) through oracle/mrgan_oracle.py in numpy fp32, %.1f s; "
-                       "noise generation included" % (n, B, D, dt))
+        def one_step():
+            il = rng.integers(0, xl.shape[0], B)
+            iu = rng.integers(0, X.shape[0], B)
+            z = rng.standard_normal((B, O.NOISE_SIZE), dtype=np.float32)
+            orc.disc_step(xl[il], yl[il], X[iu], z, noise(), noise(), noise())
+            z = rng.standard_normal((B, O.NOISE_SIZE), dtype=np.float32)
+            orc.gen_step(X[iu], z, noise(), noise())
+        return one_step
+
+    torch_threads = min(os.cpu_count(), 32)      # more threads than this only add contention on these layer sizes (measured: 256
+                                                 # threads took 56 s per step on the GPU box's host, 32 are an order of magnitude faster)
+
+    def run_torch():
+        import torch
+        torch.set_num_threads(torch_threads)
+        F = torch.nn.functional
+        g, d = O.init_params(D, seed=1, dtype=np.float32)
+        gp = [torch.tensor(p, requires_grad=True) for p in g]
+        dp = [torch.tensor(p, requires_grad=True) for p in d]
+        st = dict(t=0, mg=[torch.zeros_like(p) for p in gp], vg=[torch.zeros_like(p) for p in gp],
+                  md=[torch.zeros_like(p) for p in dp], vd=[torch.zeros_like(p) for p in dp])
+        pool = [[torch.randn(B, dims[l]) for l in range(5)] for _ in range(5)]      # pre-generated layer noise, re-used
+        zs = [torch.randn(B, O.NOISE_SIZE) for _ in range(2)]
+        Xt, xlt, ylt = torch.from_numpy(X), torch.from_numpy(xl), torch.from_numpy(yl.astype(np.int64))
+
+        def gen(z):
+            h = F.softplus(z @ gp[0] + gp[1])
+            mu, var = h.mean(0), h.var(0, unbiased=False)
+            h = gp[2] * (h - mu) / torch.sqrt(var + O.BN_EPS) + gp[3]
+            return F.softplus(h @ gp[4] + gp[5]) @ gp[6] + gp[7]
+
+        def disc(x, nz, feat=False):
+            a = x
+            for l in range(5):
+                a = torch.relu((a + O.D_SIGMAS[l] * nz[l]) @ dp[2 * l] + dp[2 * l + 1])
+            return a if feat else a @ dp[10] + dp[11]
+
+        def adam(ps, gs, ms, vs):
+            t = st['t'] + 1
+            lr_t = O.ADAM_LR * np.sqrt(1 - O.ADAM_B2 ** t) / (1 - O.ADAM_B1 ** t)
+            with torch.no_grad():
+                for p, gr, m, v in zip(ps, gs, ms, vs):
+                    m.mul_(O.ADAM_B1).add_(gr, alpha=1 - O.ADAM_B1)
+                    v.mul_(O.ADAM_B2).addcmul_(gr, gr, value=1 - O.ADAM_B2)
+                    p.sub_(lr_t * m / (v.sqrt() + O.ADAM_EPS))
+            st['t'] = t
+
+        def one_step():
+            il = torch.randint(0, xlt.shape[0], (B,))
+            iu = torch.randint(0, Xt.shape[0], (B,))
+            l_lab, l_unl = disc(xlt[il], pool[0]), disc(Xt[iu], pool[1])
+            l_fake = disc(gen(zs[0]).detach(), pool[2])
+            lse = lambda l: torch.logsumexp(l, 1)
+            loss = (-l_lab[torch.arange(B), ylt[il]].mean() + lse(l_lab).mean() - 0.5 * lse(l_unl).mean()
+                    + 0.5 * F.softplus(lse(l_unl)).mean() + 0.5 * F.softplus(lse(l_fake)).mean())
+            adam(dp, torch.autograd.grad(loss, dp), st['md'], st['vd'])
+            f_fake, f_real = disc(gen(zs[1]), pool[3], True), disc(Xt[iu], pool[4], True)
+            lg = ((f_fake.mean(0) - f_real.mean(0).detach()) ** 2).mean()
+            adam(gp, torch.autograd.grad(lg, gp), st['mg'], st['vg'])
+        return one_step
+
+    variants = {}
+    for name, make, threads in (("numpy_fp32", run_numpy, os.cpu_count()), ("torch_cpu_fp32", run_torch, torch_threads)):
+        step = make()
+        t0 = time.time()
+        step()                                                        # warm-up (thread pools, page-in) -- kept if it is all the budget allows
+        n, dt = 1, time.time() - t0
+        if dt < budget_s:
+            n, t0 = 0, time.time()
+            while True:
+                step()
+                n += 1
+                if time.time() - t0 > budget_s or n >= 64:
+                    break
+            dt = time.time() - t0
+        variants[name] = dict(value=n / dt, steps=n, seconds=round(dt, 1), threads=threads)
+    best = max(variants, key=lambda k: variants[k]["value"])
+    return dict(value=variants[best]["value"], unit="steps/s", cores=variants[best]["threads"], kind="port",
+                sample="the same workload (B=%d, D=%d), %d + %d steps in %.0f s: oracle/mrgan_oracle.py in numpy fp32 (noise drawn in the "
+                       "loop, BLAS on all %d cores) and a PyTorch-CPU fp32 module with torch.set_num_threads(%d) and pre-generated noise; value = the faster (%s)"
+                       % (B, D, variants["numpy_fp32"]["steps"], variants["torch_cpu_fp32"]["steps"],
+                          variants["numpy_fp32"]["seconds"] + variants["torch_cpu_fp32"]["seconds"], os.cpu_count(), torch_threads, best),
+                variants=variants)
 
 
 def main():
@@ -111,6 +181,8 @@ def main():
                          "discriminator layers and two generator layers of width W")
     ap.add_argument("--labeled-per-class", type=int, default=100)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: every rank takes GLOBAL / N rows of each stream (default 0: --batch rows per rank, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--local-stats", action="store_true",
@@ -140,6 +212,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of the number of ranks")
+        args.batch = args.global_batch // world
     X, y, xl, yl = build_problem(args, rank)
     B, D = args.batch, args.d
     cfg = E.default_config(D, B)
@@ -229,54 +305,84 @@ def main():
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * args.steps / elapsed
+    strong = args.global_batch > 0
+    value = (1 if strong else world) * args.steps / elapsed
     fl = algorithmic_flops(B, D, g_hidden, d_hidden)
     peak = PEAK_TFLOPS[args.dtype]
-    # dominant kernel = the GEMM kernel instantiation with the largest share of device time in the profiled pass;
-    # its algorithmic FLOPs per launch come from the library (2 x logical M*N*K of each dense-layer product)
+    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)                       # FLOP per byte at which the two roofs meet (312 for bf16)
     P = float(args.profile_steps)
-    gemms = {k: v for k, v in prof.items() if k.startswith("gemm_")}
-    dom = max(gemms, key=lambda k: gemms[k][0])
-    dom_ms, dom_launches, dom_flops = gemms[dom]
-    per_launch_flops = dom_flops / max(dom_launches, 1)
-    per_launch_s = 1e-3 * dom_ms / max(dom_launches, 1)
-    achieved = per_launch_flops / per_launch_s / 1e12
-    gemm_ms = sum(v[0] for v in gemms.values()) / P
-    gemm_flops = sum(v[2] for v in gemms.values()) / P
+
+    def line(ms, launches, flops, nbytes):
+        """roofline entry of one kernel (or family) from its live-measured time and its ALGORITHMIC work"""
+        sec = 1e-3 * ms
+        ai = flops / nbytes if nbytes > 0 else None
+        d = {"ms_per_step": round(ms / P, 4), "launches_per_step": launches / P,
+             "algorithmic_gflop_per_launch": round(flops / max(launches, 1) / 1e9, 3),
+             "algorithmic_mb_per_launch": round(nbytes / max(launches, 1) / 1e6, 2) if nbytes > 0 else None,
+             "flop_per_byte": round(ai, 1) if ai else None}
+        if flops > 0 and (ai is None or ai >= ridge):
+            d.update(bound="mfma", achieved=round(flops / sec / 1e12, 2), peak=peak, unit="TFLOP/s", frac=round(flops / sec / 1e12 / peak, 4))
+        elif nbytes > 0:
+            d.update(bound="hbm", achieved=round(nbytes / sec / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(nbytes / sec / 1e9 / PEAK_HBM_GBS, 4))
+            if flops > 0:
+                d["tflops"] = round(flops / sec / 1e12, 2)
+        return d
+
+    def family(k):
+        if k.startswith("gemm_bf16_kc_kernel<0") or k.startswith("gemm_f32_kernel<0"):
+            return "kc_forward"
+        if k.startswith("gemm_bf16_kc_kernel<1") or k.startswith("gemm_f32_kernel<1"):
+            return "kc_input_gradient"
+        if k.startswith("gemm_bf16_ks") or k.startswith("gemm_f32_kernel<2"):
+            return "ks_weight_gradient"
+        if k.startswith("chain_kernel"):
+            return "row_block_chain"
+        return "elementwise"
+    fams = {}
+    for k, v in prof.items():
+        f = fams.setdefault(family(k), [0.0, 0, 0.0, 0.0])
+        for i in range(4):
+            f[i] += v[i]
+    # dominant kernel = the instantiation with the largest share of device time in the profiled pass
+    work = {k: v for k, v in prof.items() if v[2] > 0}
+    dom = max(work, key=lambda k: work[k][0])
     all_ms = sum(v[0] for v in prof.values()) / P
-    # HBM bytes per launch of that kernel from the committed PMC summary (scripts/traffic.sh; separate --pmc passes,
-    # gfx950 FETCH_SIZE correction applied there); null if the summary has no row for it
+    # HBM bytes per launch of that kernel from the committed PMC summary (scripts/traffic.sh; separate --pmc passes, gfx950
+    # FETCH_SIZE correction applied there).  The summary is keyed by the full instantiation name (template arguments included)
+    # and carries the commit it was measured on; null when it has no row for exactly this instantiation.
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world == 1 and os.path.exists(tfile):
-        row = json.load(open(tfile)).get(dom)
+    tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if world == 1 and not args.hidden and os.path.exists(tfile):
+        tj = json.load(open(tfile))
+        row = tj.get("kernels", {}).get(dom)
         if row:
-            traffic = {"hbm_bytes_per_launch": round(row["hbm_bytes_per_launch"]), "source": "profiles/r01_traffic.json"}
-    roofline = {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-        "traffic": traffic,
-        "kernel": dom, "launches_per_step": dom_launches / P,
+            traffic = {"hbm_bytes_per_launch": round(row["hbm_bytes_per_launch"]), "source": "profiles/r02_traffic.json",
+                       "measured_at_commit": tj.get("commit")}
+    roofline = line(*prof[dom])
+    roofline.update({
+        "kernel": dom, "traffic": traffic,
         "timing": "hipEvent (start, stop) pairs stamped at each kernel's begin and end on the launch stream "
                   "(hipExtLaunchKernelGGL inside the library), profiled pass of %d steps after the timed region" % args.profile_steps,
-        "avg_launch_us": round(1e6 * per_launch_s, 2), "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3),
-        "all_gemm_kernels": {"achieved": round(gemm_flops / (1e-3 * gemm_ms) / 1e12, 2), "ms_per_step": round(gemm_ms, 4),
-                             "algorithmic_gflop_per_step": round(gemm_flops / 1e9, 2)},
+        "avg_launch_us": round(1e3 * prof[dom][0] / max(prof[dom][1], 1), 2),
+        "bound_rule": "mfma if algorithmic FLOP per algorithmic byte >= %.0f (= %.0f TFLOP/s / %.0f GB/s), else hbm" % (ridge, peak, PEAK_HBM_GBS),
+        "families": {k: line(*v) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
         "step": {"algorithmic_gflop": round(fl["total"] / 1e9, 2), "achieved": round(fl["total"] / (elapsed / args.steps) / 1e12, 2),
-                 "frac": round(fl["total"] / (elapsed / args.steps) / 1e12 / peak, 4),
+                 "peak": peak, "unit": "TFLOP/s", "frac": round(fl["total"] / (elapsed / args.steps) / 1e12 / peak, 4),
+                 "launches": sum(v[1] for v in prof.values()) / P,
                  "kernel_ms": {k: round(v[0] / P, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-                 "launches": {k: v[1] / P for k, v in prof.items()},
+                 "kernel_launches": {k: v[1] / P for k, v in prof.items()},
                  "all_kernels_ms": round(all_ms, 4)},
-    }
+    })
     out = {
         "metric": "GAN train steps/sec (labeled+unlabeled+G) at batch 4096", "value": round(value, 2), "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s: synthetic N=%d x D=%d, K=6, batch %d per GPU, labeled %d/class; one step = "
                                "D sub-step (3B rows) + G sub-step (2B rows) + both Adam updates"
                                % ("BASELINE configs[4] geometry (hidden %d x 5, generator %d x 2) on one GPU" % (args.hidden, args.hidden)
                                   if args.hidden else "BASELINE configs[1]", args.rows, D, B, args.labeled_per_class),
-                   "global_batch": B * world, "parallelism": "dp%d" % world if world > 1 else "single",
+                   "global_batch": B * world, "rows_per_gpu": B, "parallelism": "dp%d" % world if world > 1 else "single",
                    "batch_statistics": ("local_stats (per shard)" if args.local_stats else "synced over ranks") if world > 1 else "n/a",
                    "launch": "eager phases + RCCL all-reduce" if world > 1 else ("eager" if args.no_graph else "hipGraph replay")},
         "roofline": roofline,

@@ -153,11 +153,12 @@ int mrgan_read_metrics(mrgan_handle* h, float* out8_host, int reset, mrgan_strea
  * (hipExtLaunchKernelGGL), i.e. the interval rocprofv3's kernel trace reports; mrgan_train_pair launches eagerly
  * (no graph replay) behind a short delay kernel per sub-step so that the kernels still run back to back.
  * mrgan_profile_end returns, per distinct kernel instantiation (named as rocprofv3 prints it, MRGAN_PROF_NAME_LEN
- * bytes each): summed time, launch count and summed ALGORITHMIC flops (2 x logical M*N*K of the dense layer). */
+ * bytes each): summed time, launch count, summed ALGORITHMIC flops (2 x logical M*N*K of the dense layer) and summed
+ * ALGORITHMIC bytes (operands read once + outputs written once; 0 where the library does not account them). */
 enum { MRGAN_PROF_NAME_LEN = 96 };
 int mrgan_profile_begin(mrgan_handle* h);
 int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, int max_kernels, char* names, float* ms, int32_t* launches,
-                      double* flops, int* n_kernels);
+                      double* flops, double* bytes, int* n_kernels);
 
 /* diagnostics used by the parity tests */
 int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,

@@ -63,7 +63,7 @@ struct Dense {
     float* slabs; int splits;   // weight-gradient slabs [nseg*splits][Kp][Np]
 };
 
-struct ProfRec { int cat; hipEvent_t start, stop; double flops; };      // device-side begin / end of one kernel (MRGAN_LAUNCH)
+struct ProfRec { int cat; hipEvent_t start, stop; double flops, bytes; };      // device-side begin / end of one kernel (MRGAN_LAUNCH)
 
 struct Arena {
     char* base = nullptr; size_t off = 0, cap = 0;
@@ -398,20 +398,22 @@ void prof_arm(mrgan_handle* h) {
     lt.armed = 1;
 }
 // ... and book the launch it timed under `name`
-void prof_done(mrgan_handle* h, const char* name, double flops) {
+// flops / bytes: ALGORITHMIC work of the launch (2 x logical M N K; operands read once + outputs written once)
+void prof_done(mrgan_handle* h, const char* name, double flops, double bytes = 0.0) {
     if (!h->prof) return;
     LaunchTimer& lt = g_launch_timer;
-    if (lt.fired) h->prof_recs.push_back(ProfRec{prof_cat(h, name), lt.start, lt.stop, flops});
+    if (lt.fired) h->prof_recs.push_back(ProfRec{prof_cat(h, name), lt.start, lt.stop, flops, bytes});
     else if (lt.armed) { hipEventDestroy(lt.start); hipEventDestroy(lt.stop); }
     lt.armed = lt.fired = 0;
 }
-#define PROF(name, call)            \
-    do {                            \
-        prof_arm(h);                \
-        const int prc_ = (call);    \
-        prof_done(h, name, 0);      \
-        CHK(prc_);                  \
+#define PROFB(name, call, bytes)            \
+    do {                                    \
+        prof_arm(h);                        \
+        const int prc_ = (call);            \
+        prof_done(h, name, 0, bytes);       \
+        CHK(prc_);                          \
     } while (0)
+#define PROF(name, call) PROFB(name, call, 0.0)
 
 // ------------------------------------------------------------------------------------------------
 // GEMM call sites
@@ -420,7 +422,10 @@ int run_gemm(mrgan_handle* h, int epi, const GemmArgs& g, double algo_flops, hip
     const char* kname = "gemm";
     prof_arm(h);
     const int r = h->bf16 ? launch_gemm_bf16(epi, g, s, &kname) : launch_gemm_f32(epi, g, s, &kname);
-    prof_done(h, kname, algo_flops);
+    const double es = h->es;
+    const double bytes = epi == EPI_SLAB ? ((double)g.K * g.M + (double)g.K * g.N) * es + (double)g.splits * g.M * g.N * 4.0
+                                         : ((double)g.nbatch * g.M * (g.K + g.N) + (double)g.K * g.N) * es;
+    prof_done(h, kname, algo_flops, bytes);
     CHK(r);
     return 0;
 }
@@ -509,7 +514,9 @@ int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, 
         const char* kname = "gemm";
         prof_arm(h);
         const int r = launch_gemm_bf16_dw_group(gs, n, s, &kname, fold);
-        prof_done(h, kname, total);
+        double bytes = 0.0;
+        for (int i = 0; i < n; ++i) bytes += ((double)gs[i].K * gs[i].M + (double)gs[i].K * gs[i].N) * 2.0 + (double)gs[i].splits * gs[i].M * gs[i].N * 4.0;
+        prof_done(h, kname, total, bytes);
         if (r < 0) return fail(r, "grouped weight-gradient launch failed");
         if (r == 0) return 0;
     }
@@ -535,7 +542,14 @@ int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t 
         a.step_out = h->step_out; a.accum = h->accum;
         a.flat_tail = h->flat_d + h->flat_d_n;
     }
-    PROF("adam_kernel", launch_adam(a, s));
+    {
+        // Keras Adam reads p, m, v and the gradient and writes p, m, v: 28 B per parameter (+ the extra gradient slabs and the
+        // two bf16 weight copies of the bf16 mode)
+        const std::vector<Tensor>& ts = net == MRGAN_NET_D ? h->dt : h->gt;
+        double bytes = 0.0;
+        for (const Tensor& t : ts) bytes += (double)t.prow * t.pcol * (24.0 + 4.0 * std::max(1, t.nslab) + (t.w16 ? 4.0 : 0.0));
+        PROFB("adam_kernel", launch_adam(a, s), bytes);
+    }
     return 0;
 }
 
@@ -654,7 +668,12 @@ int run_chain(mrgan_handle* h, const ChainArgs& c0, double flops, hipStream_t s)
                         tot[2] / nb / 1e3, tot[3] / nb / 1e3, tot[4] / nb / 1e3, tot[5] / nb / 1e3, tot[6] / nb / 1e3, tot[7] / nb / 1e3);
     }
 #endif
-    prof_done(h, "chain_kernel", flops);
+    double bytes = 0.0;                    // first A image + every product's weights and stored output (bf16)
+    if (c.a_kind == CH_A_GLOBAL) bytes += (double)c.rows * c.nseg * c.a_cols * 2.0;
+    for (int i = 0; i < c.nops; ++i)
+        if (c.op[i].kind == CH_OP_GEMM) bytes += ((double)c.op[i].K * c.op[i].N + (double)c.rows * c.nseg * c.op[i].N) * 2.0;
+    static const char* names[3] = {"chain_kernel<0>", "chain_kernel<1>", "chain_kernel<2>"};     // as rocprofv3 prints them
+    prof_done(h, names[c.variant], flops, bytes);
     CHK(r);
     return 0;
 }
@@ -1211,17 +1230,17 @@ int mrgan_profile_begin(mrgan_handle* h) {
 }
 
 int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, int max_kernels, char* names, float* ms, int32_t* launches,
-                      double* flops, int* n_kernels) {
-    if (!h || !names || !ms || !launches || !flops || !n_kernels) return fail(-1, "null argument");
+                      double* flops, double* bytes, int* n_kernels) {
+    if (!h || !names || !ms || !launches || !flops || !bytes || !n_kernels) return fail(-1, "null argument");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     const int n = std::min(max_kernels, (int)h->prof_names.size());
     for (int i = 0; i < n; ++i) {
-        ms[i] = 0.f; launches[i] = 0; flops[i] = 0.0;
+        ms[i] = 0.f; launches[i] = 0; flops[i] = 0.0; bytes[i] = 0.0;
         snprintf(names + (size_t)i * MRGAN_PROF_NAME_LEN, MRGAN_PROF_NAME_LEN, "%s", h->prof_names[i].c_str());
     }
     for (const ProfRec& r : h->prof_recs) {
         float t = 0.f;
-        if (r.cat < n && hipEventElapsedTime(&t, r.start, r.stop) == hipSuccess) { ms[r.cat] += t; launches[r.cat] += 1; flops[r.cat] += r.flops; }
+        if (r.cat < n && hipEventElapsedTime(&t, r.start, r.stop) == hipSuccess) { ms[r.cat] += t; launches[r.cat] += 1; flops[r.cat] += r.flops; bytes[r.cat] += r.bytes; }
     }
     for (auto& r : h->prof_recs) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
     h->prof_recs.clear(); h->prof_names.clear();

@@ -272,16 +272,16 @@ class Engine(object):
         _check(self.lib.mrgan_profile_begin(self.handle))
 
     def profile_end(self, max_kernels=64):
-        """-> {kernel instantiation name: (total ms, launches, algorithmic flops)} since profile_begin"""
+        """-> {kernel instantiation name: (total ms, launches, algorithmic flops, algorithmic bytes)} since profile_begin"""
         names = C.create_string_buffer(max_kernels * PROF_NAME_LEN)
         ms, cnt = (C.c_float * max_kernels)(), (C.c_int32 * max_kernels)()
-        fl, n = (C.c_double * max_kernels)(), C.c_int()
-        _check(self.lib.mrgan_profile_end(self.handle, _stream(), max_kernels, names, ms, cnt, fl, C.byref(n)))
+        fl, by, n = (C.c_double * max_kernels)(), (C.c_double * max_kernels)(), C.c_int()
+        _check(self.lib.mrgan_profile_end(self.handle, _stream(), max_kernels, names, ms, cnt, fl, by, C.byref(n)))
         out = {}
         for i in range(n.value):
             name = names.raw[i * PROF_NAME_LEN:(i + 1) * PROF_NAME_LEN].split(b"\0")[0].decode()
             if name != "(start)":
-                out[name] = (ms[i], cnt[i], fl[i])
+                out[name] = (ms[i], cnt[i], fl[i], by[i])
         return out
 
     def region(self, which):
