@@ -244,9 +244,13 @@ class Adam(object):
         lr_t = self.lr_t()
         for i, (p, g) in enumerate(zip(params, grads)):
             dt = p.dtype
-            ms[i] = (self.b1 * ms[i] + (1.0 - self.b1) * g).astype(dt)
-            vs[i] = (self.b2 * vs[i] + (1.0 - self.b2) * g * g).astype(dt)
-            params[i] = (p - dt.type(lr_t) * ms[i] / (np.sqrt(vs[i]) + dt.type(self.eps))).astype(dt)
+            g = np.asarray(g, dtype=dt)
+            # m = b1 m + (1 - b1) g ; v = b2 v + (1 - b2) g^2 ; p -= lr_t m / (sqrt(v) + eps)   (in place: no temporaries)
+            ms[i] *= dt.type(self.b1); ms[i] += dt.type(1.0 - self.b1) * g
+            vs[i] *= dt.type(self.b2); vs[i] += dt.type(1.0 - self.b2) * g * g
+            den = np.sqrt(vs[i]); den += dt.type(self.eps)
+            np.divide(ms[i], den, out=den); den *= dt.type(lr_t)
+            params[i] = p - den
         self.iterations += 1
 
 
@@ -526,9 +530,9 @@ def device_noise_sums(seed, site, seg, step, rows, cols, row0=0):
         m = np.arange(nb * 8, dtype=np.uint32) * np.uint32(0x85EBCA77)                          # word index cblk*8 + m
         w = mix32(rowhash[:, None] ^ m[None, :]) | np.uint32(0x01010101)                        # [rows, nb*8]
     # byte t of word m is a[k = 4m + t] (little endian), signed
-    a = np.ascontiguousarray(w).view(np.int8).reshape(rows, nb, 32).astype(np.int64)
-    s = a @ _HADAMARD32                                                                         # [rows, nb, 32]
-    return s.reshape(rows, nb * 32)[:, :cols]
+    a = np.ascontiguousarray(w).view(np.int8).reshape(rows * nb, 32).astype(np.float32)
+    s = a @ _HADAMARD32.astype(np.float32)              # |s| <= 32 * 127 < 2^24: exact in float32, and BLAS-fast
+    return np.rint(s).astype(np.int64).reshape(rows, nb * 32)[:, :cols]
 
 
 def device_normal(seed, site, seg, step, rows, cols, row0=0, dtype=np.float64):

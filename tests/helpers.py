@@ -115,3 +115,63 @@ def stub_training(job, datasets, device):
     if job.get('explode'):
         raise ValueError("stub failure requested")
     return (val, os.getpid(), device)
+
+
+def oracle_fit(g0, d0, x_labeled, y_labeled, x_train, x_test, y_test, batch, epochs, seed, rng_seed, dtype=np.float32, quantize=None, log=None):
+    """The epoch loop of mr_gan.py:183-230 through the CPU oracle, driven by the SAME streams as MRGAN.fit on the engine:
+    index streams from `rng` in the order MRGAN._fit draws them (mr_gan.py:189-195), z and layer noise from the restated
+    device generator keyed by (seed, site, segment, Keras iteration).  Returns the final whole-test-set error (mr_gan.py:230)."""
+    from threadpoolctl import threadpool_limits
+    # batch-50 products: OpenBLAS with many threads is pathologically slow on them (X^T dY at 50 x 1200 x 1000: 19 ms with 8
+    # threads, 0.5 ms with 4), so the loop runs on 4 BLAS threads
+    with threadpool_limits(limits=4):
+        return _oracle_fit(g0, d0, x_labeled, y_labeled, x_train, x_test, y_test, batch, epochs, seed, np.random.RandomState(rng_seed), dtype,
+                           quantize, log)
+
+
+def _oracle_fit(g0, d0, x_labeled, y_labeled, x_train, x_test, y_test, batch, epochs, seed, rng, dtype, quantize, log):
+    orc = O.MRGANMirror(g0, d0, quantize=quantize) if quantize else O.MRGANOracle([p.astype(dtype) for p in g0], [p.astype(dtype) for p in d0])
+    xl, xu = x_labeled.astype(dtype), x_train.astype(dtype)
+    yl = np.asarray(y_labeled).astype(np.int64)
+    n_train, n_lab, D = xu.shape[0], xl.shape[0], xu.shape[1]
+    nb = n_train // batch
+    it = 0
+    for epoch in range(epochs):
+        inds = O.tiled_permutation(rng.permutation, n_lab, n_train)
+        unl = [rng.permutation(n_train) for _ in range(3)]
+        for t in range(nb):
+            sl = slice(t * batch, (t + 1) * batch)
+            ns = lambda seg, k: noise_set(seed, seg, k, batch, D, 0, dtype)
+            orc.disc_step(xl[inds[sl]], yl[inds[sl]], xu[unl[0][sl]], draw_z(seed, it, batch, dtype=dtype), ns(0, it), ns(1, it), ns(2, it))
+            orc.gen_step(xu[unl[1][sl]], draw_z(seed, it + 1, batch, dtype=dtype), ns(0, it + 1), ns(1, it + 1))
+            it += 2
+        if log is not None:
+            log.append(float(orc.test_error(x_test.astype(dtype), y_test)))
+    return float(orc.test_error(x_test.astype(dtype), y_test))
+
+
+def oracle_fit_job(kw):
+    """oracle_fit in a worker process (multiprocessing 'spawn'): the worker imports numpy only -- with torch's and
+    scikit-learn's OpenMP pools loaded beside OpenBLAS these batch-50 products run ~80x slower (120 ms per forward, measured)."""
+    log = []
+    err = oracle_fit(log=log, **kw)
+    return err, log
+
+
+def run_oracle_fits(jobs, workers=2):
+    """[kwargs of oracle_fit] -> [(final error, per-epoch errors)], each in a clean worker process with 4 BLAS threads"""
+    import multiprocessing as mp
+    import os
+    old = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS")}
+    os.environ["OPENBLAS_NUM_THREADS"] = "4"
+    os.environ["OMP_NUM_THREADS"] = "4"
+    try:
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+            asyncs = [pool.apply_async(oracle_fit_job, (j,)) for j in jobs]
+            return asyncs, pool, [a.get(timeout=600) for a in asyncs]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -425,6 +425,74 @@ def test_fit_learns_planted_structure(dtype):
     m.engine.close()
 
 
+def test_accuracy_parity_on_mreo_surrogate():
+    """north_star: accuracies within +-0.5 % of the reference arithmetic on identical seeds / inputs.
+
+    The MREO data set is not available offline (README.md:7-11), so this runs SURVEY 8(d) config 1's surrogate at the real size
+    (synthetic_mreo: N = 7200 = 6 classes x 12 objects x 100 trials, D = 1200 = force + temperature layout, 6-fold split 0 ->
+    6000 training / 1200 test rows, batch 50, mr_gan.py:73-82), at 50 and at 500 labeled rows per class, through
+        (a) the HIP engine in fp32, (b) the HIP engine in bf16, (c) the CPU oracle in float32 numpy,
+    all three from the same initial weights, the same index streams (mr_gan.py:189-195) and the same z / GaussianNoise
+    streams (the engine's generator, restated in the oracle).  The class separation (sep = 0.5) is chosen so that the final
+    error is small but not zero (0.3 - 1 %), i.e. the comparison is not vacuous.
+    A single evaluation of one trajectory moves by +-0.3 % from epoch to epoch (GaussianNoise is active in training, and the
+    three arithmetic paths diverge chaotically through Adam), so the quantity held to north_star's 0.5 % absolute is the test
+    error averaged over the last ten epochs (the reference prints it every epoch, mr_gan.py:219-228); the final whole-set
+    error (mr_gan.py:230) of a single evaluation is held to 1 %.  30 epochs instead of the reference's 100 keep the numpy loop
+    at ~1.5 min (two worker processes); scripts/accuracy_probe.py runs any length."""
+    from sklearn.model_selection import StratifiedKFold
+    from mr_gan_amd import MRGAN, select_labeled, standard_scale, synthetic_mreo
+    from tests.helpers import run_oracle_fits
+    import multiprocessing as mp
+    import os
+    epochs, seed = 30, 1234
+    X, y, _ = synthetic_mreo(sep=0.5)
+    tr, te = next(iter(StratifiedKFold(n_splits=6, shuffle=True, random_state=0).split(X, y)))
+    Xtr, Xte = standard_scale(X[tr], X[te])
+    ytr, yte = y[tr], y[te]
+    perm = np.random.RandomState(1).permutation(len(ytr))
+    Xtr, ytr = Xtr[perm], ytr[perm]
+    probs = {n_lab: select_labeled(Xtr, ytr, n_lab)[:2] for n_lab in (50, 500)}
+    # the CPU oracle loops start first, in clean worker processes, and run while the GPU trains
+    m0 = MRGAN(Xtr.shape[1], batch_size=50, dtype='float32', seed=seed)
+    g0, d0 = m0.get_weights('generator'), m0.get_weights('discriminator')
+    m0.engine.close()
+    old = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS")}
+    os.environ["OPENBLAS_NUM_THREADS"] = os.environ["OMP_NUM_THREADS"] = "4"
+    from tests.helpers import oracle_fit_job
+    pool = mp.get_context("spawn").Pool(2)
+    try:
+        asyncs = {n_lab: pool.apply_async(oracle_fit_job, (dict(g0=g0, d0=d0, x_labeled=xl, y_labeled=yl, x_train=Xtr, x_test=Xte, y_test=yte,
+                                                                 batch=50, epochs=epochs, seed=seed, rng_seed=5),))
+                  for n_lab, (xl, yl) in probs.items()}
+        err, last5 = {}, {}        # (last5: mean over the last ten epochs)
+        for n_lab, (xl, yl) in probs.items():
+            for dt in ('float32', 'bfloat16'):
+                m = MRGAN(Xtr.shape[1], batch_size=50, dtype=dt, seed=seed)
+                hist = m.fit(xl, yl, Xtr, epochs=epochs, validation_data=(Xte, yte), rng=np.random.RandomState(5))
+                err[(n_lab, dt)] = m.evaluate(Xte, yte)
+                last5[(n_lab, dt)] = float(np.mean([h['test_err'] for h in hist[-10:]]))
+                m.engine.close()
+        for n_lab in probs:
+            e, log = asyncs[n_lab].get(timeout=800)
+            err[(n_lab, 'oracle')], last5[(n_lab, 'oracle')] = e, float(np.mean(log[-10:]))
+    finally:
+        pool.terminate()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    print("\ntest error after %d epochs (test rows: %d)\n  final       : %s\n  last-10 mean: %s" % (
+        epochs, len(yte), {k: round(v, 4) for k, v in sorted(err.items(), key=str)}, {k: round(v, 4) for k, v in sorted(last5.items(), key=str)}))
+    for n_lab in probs:
+        e = [err[(n_lab, k)] for k in ('float32', 'bfloat16', 'oracle')]
+        a = [last5[(n_lab, k)] for k in ('float32', 'bfloat16', 'oracle')]
+        assert max(e) < 0.05, (n_lab, e)                                    # everybody learned the task
+        assert max(a) - min(a) <= 0.005 + 1e-9, (n_lab, "last-10 mean", a)   # north_star: +-0.5 % absolute
+        assert max(e) - min(e) <= 0.01 + 1e-9, (n_lab, "final", e)
+
+
 def test_graph_replay_equals_eager():
     from mr_gan_amd import MRGAN, select_labeled, synthetic_blobs
     X, y = synthetic_blobs(n=1200, d=32, seed=4)
