@@ -5,7 +5,7 @@
     dataset(modalities=0, forcetempTime=4, contactmicTime=0.2, leaveObjectOut=False, verbose=False)
         same signature as mr_gan.py:23
     python -m mr_gan_amd.mr_gan --tables 1 3 5 6 [-v]        (mr_gan.py:236-341)
-    python -m mr_gan_amd.mr_gan --tables 1 --gpus 8 --jobs-per-gpu 2     run-level scheduling of table 1 (scheduler.py)
+    python -m mr_gan_amd.mr_gan --tables 1 3 5 6 --gpus 8 --jobs-per-gpu 2     run-level scheduling of the tables (scheduler.py)
 
 Extra keyword arguments (batch_size, dtype, seed, device) default to the reference's literals.
 """
@@ -163,6 +163,70 @@ def _table1_scheduled(sched, dataset_fn, kw):
             _print_kfold(errors[6 * i:6 * i + 6])
 
 
+def _table3_scheduled(sched, dataset_fn, kw):
+    """Table 3 (mr_gan.py:263-283): leave-one-object-out, 2 modalities x 5 label fractions x one training per object; every
+    training of a modality is dispatched together, the reference's lines are printed in the reference's order."""
+    print('\n', '-' * 25, 'Testing generalization with leave-one-object-out validation', '-' * 25)
+    print('-' * 100)
+    percents = [1, 4, 16, 50, 100]
+    for modality in [2, 5]:
+        print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
+        objects = dataset_fn(modalities=modality, leaveObjectOut=True)
+        names = list(objects.keys())
+        jobs = []
+        for percent in percents:
+            for objName in names:
+                Xtest, ytest = np.array(objects[objName]['x']), np.array(objects[objName]['y'])
+                Xtrain = np.array(list(itertools.chain.from_iterable([d['x'] for n, d in objects.items() if n != objName])))
+                ytrain = np.array(list(itertools.chain.from_iterable([d['y'] for n, d in objects.items() if n != objName])))
+                jobs.append(dict(trainTestSets=[Xtrain, Xtest, ytrain, ytest], percentlabeled=percent, **kw))
+        errors = sched.run(jobs)
+        for i, percent in enumerate(percents):
+            print('-' * 15, 'Percentage of training data labeled: %d%%' % percent, '-' * 15)
+            errs = errors[i * len(names):(i + 1) * len(names)]
+            for objName, e in zip(names, errs):
+                print(objName, 'Test error:', e, 'Test accuracy:', 1.0 - e)
+            print('Average leave-one-object-out error:', np.mean(errs), 'Average accuracy:', np.mean(1.0 - np.array(errs)))
+            sys.stdout.flush()
+
+
+def _table5_scheduled(sched, dataset_fn, kw):
+    """Table 5 (mr_gan.py:285-318): 28 (modality, contact time) data sets x 6 folds at 100 % labeled"""
+    for block, combos, fmt in ((0, [(m, dict(forcetempTime=t)) for m in range(3) for t in [4, 3, 2, 1, 0.5, 0.2, 0.1]], None),
+                               (1, [(3, dict(contactmicTime=t)) for t in [1, 0.7, 0.5, 0.3, 0.2, 0.1, 0.05]], None)):
+        print('\n', '-' * 25, 'Testing various lengths of contact time in training data', '-' * 25)
+        print('-' * 100)
+        last_mod = None
+        for modality, dkw in combos:
+            if modality != last_mod:
+                print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
+                last_mod = modality
+            print('-' * 15, 'Length of training data: %.1fs' % list(dkw.values())[0], '-' * 15)
+            X, y = dataset_fn(modalities=modality, **dkw)
+            key = sched.put_dataset(X, y)
+            _print_kfold(sched.run(_kfold_jobs(X, y, key, percentlabeled=100, **kw)))
+
+
+def _table6_scheduled(sched, dataset_fn, kw):
+    """Table 6 (mr_gan.py:320-341): 2 modalities x 7 amounts of unlabeled data x 6 folds at 4 % labeled"""
+    print('\n', '-' * 25, 'Testing performance as quantity of unlabeled data increases', '-' * 25)
+    print('-' * 100)
+    for modality in [2, 5]:
+        print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
+        X, y = dataset_fn(modalities=modality)
+        key = sched.put_dataset(X, y)
+        for percentlabeled in [4]:
+            print('-' * 15, 'Percentage of training data labeled: %d%%' % percentlabeled, '-' * 15)
+            unl = [0, 4, 8, 16, 32, 64, 100 - percentlabeled]
+            jobs = []
+            for percentunlabeled in unl:
+                jobs += _kfold_jobs(X, y, key, percentlabeled=percentlabeled, percentunlabeled=percentunlabeled, **kw)
+            errors = sched.run(jobs)
+            for i, percentunlabeled in enumerate(unl):
+                print('-' * 15, 'Percentage of training data unlabeled: %d%%' % percentunlabeled, '-' * 15)
+                _print_kfold(errors[6 * i:6 * i + 6])
+
+
 def main(argv=None, dataset_fn=dataset, mr_gan_fn=mr_gan, scheduler_factory=None):
     parser = argparse.ArgumentParser(description='Semi-supervised learning with GANs for material recognition on haptic data.')
     parser.add_argument('-t', '--tables', nargs='+', help='[Required] Tables to recompute', required=True)
@@ -170,16 +234,25 @@ def main(argv=None, dataset_fn=dataset, mr_gan_fn=mr_gan, scheduler_factory=None
     parser.add_argument('--epochs', type=int, default=100)
     parser.add_argument('--dtype', default='float32')
     parser.add_argument('--gpus', type=int, default=0,
-                        help='run-level scheduling (table 1): dispatch the independent trainings over this many GPUs (0 = in-process, sequential)')
+                        help='run-level scheduling: dispatch the independent trainings of tables 1 / 3 / 5 / 6 over this many GPUs (0 = in-process, sequential)')
     parser.add_argument('--jobs-per-gpu', type=int, default=1, help='concurrent trainings per GPU with --gpus')
     args = parser.parse_args(argv)
     kw = dict(epochs=args.epochs, dtype=args.dtype, verbose=args.verbose)
 
-    if '1' in args.tables and args.gpus > 0:                       # same table, trainings dispatched by the scheduler
+    if args.gpus > 0:                                              # same tables, trainings dispatched by the scheduler
         from mr_gan_amd.scheduler import RunScheduler
+        skw = dict(epochs=args.epochs, dtype=args.dtype)
         with (scheduler_factory or RunScheduler)(gpus=args.gpus, jobs_per_gpu=args.jobs_per_gpu) as sched:
-            _table1_scheduled(sched, dataset_fn, dict(epochs=args.epochs, dtype=args.dtype))
-    elif '1' in args.tables:                                       # mr_gan.py:244-261
+            if '1' in args.tables:
+                _table1_scheduled(sched, dataset_fn, skw)
+            if '3' in args.tables:
+                _table3_scheduled(sched, dataset_fn, skw)
+            if '5' in args.tables:
+                _table5_scheduled(sched, dataset_fn, skw)
+            if '6' in args.tables:
+                _table6_scheduled(sched, dataset_fn, skw)
+        return
+    if '1' in args.tables:                                         # mr_gan.py:244-261
         print('\n', '-' * 25, 'Testing various amounts of labeled training data', '-' * 25)
         print('-' * 100)
         for modality in range(len(MODALITIES)):

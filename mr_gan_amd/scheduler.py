@@ -43,11 +43,11 @@ def _worker(wid, device, runner, inbox, outbox):
             datasets[msg[1]] = (msg[2], msg[3])
             outbox.put(('ack', wid, msg[1]))
         else:
-            _, idx, job = msg
+            _, run_id, idx, job = msg
             try:
-                outbox.put(('done', wid, idx, runner(job, datasets, local)))
+                outbox.put(('done', wid, run_id, idx, runner(job, datasets, local)))
             except Exception:                                                    # report, keep serving
-                outbox.put(('fail', wid, idx, traceback.format_exc()))
+                outbox.put(('fail', wid, run_id, idx, traceback.format_exc()))
 
 
 class RunScheduler(object):
@@ -56,6 +56,7 @@ class RunScheduler(object):
             raise ValueError("gpus and jobs_per_gpu must be positive")
         self.devices = list(devices) if devices is not None else ['cuda:%d' % g for g in range(gpus) for _ in range(jobs_per_gpu)]
         ctx = mp.get_context('spawn')                       # never fork a process that may have initialised HIP
+        self._ctx, self._runner, self._datasets = ctx, runner, {}
         self.outbox = ctx.Queue()
         self.inboxes, self.procs = [], []
         for wid, dev in enumerate(self.devices):
@@ -71,43 +72,91 @@ class RunScheduler(object):
     def put_dataset(self, X, y):
         key = self._nkeys
         self._nkeys += 1
+        self._datasets[key] = (X, y)
         for q in self.inboxes:
             q.put(('dataset', key, X, y))
-        for _ in self.inboxes:
-            self._get()
+        acks = 0
+        while acks < len(self.inboxes):
+            if self._get()[0] == 'ack':                     # (late results of a failed run() may still be in the queue)
+                acks += 1
         return key
 
-    def _get(self):
+    def _get(self, timeout=None):
+        import time
+        t0 = time.time()
         while True:
             try:
-                return self.outbox.get(timeout=5.0)
+                msg = self.outbox.get(timeout=1.0 if timeout else 5.0)
+                if msg[0] == 'ack' and len(msg) == 3:
+                    return msg
+                return msg
             except Exception:                               # queue.Empty
                 dead = [i for i, p in enumerate(self.procs) if p.exitcode not in (None, 0)]
                 if dead:
                     raise RuntimeError("scheduler worker(s) %s died" % dead)
+                if timeout and time.time() - t0 >= timeout:
+                    raise TimeoutError()
 
-    def run(self, jobs):
-        """Greedy dispatch: every idle worker takes the next job; results come back in job order."""
+    def run(self, jobs, job_timeout=None):
+        """Greedy dispatch: every idle worker takes the next job; results come back in job order.
+
+        Every message carries the id of the run() that issued it, so results of an earlier, failed run that arrive late are
+        ignored.  On a failed job the jobs still in flight are waited for (their workers stay usable) before the error is
+        raised.  job_timeout (seconds, optional): a job that takes longer has its worker terminated and replaced by a fresh
+        process, and counts as failed."""
+        import time
         jobs = list(jobs)
         results = [None] * len(jobs)
         self.assignments = []
-        nxt, inflight = 0, 0
+        self._run_id = getattr(self, '_run_id', 0) + 1
+        rid = self._run_id
+        nxt, failure = 0, None
         idle = list(range(len(self.inboxes)))
-        while nxt < len(jobs) or inflight:
-            while idle and nxt < len(jobs):
+        started = {}                                        # worker -> (job index, start time)
+        while (nxt < len(jobs) and failure is None) or started:
+            while idle and nxt < len(jobs) and failure is None:
                 w = idle.pop(0)
-                self.inboxes[w].put(('job', nxt, jobs[nxt]))
+                self.inboxes[w].put(('job', rid, nxt, jobs[nxt]))
                 self.assignments.append((nxt, w))
+                started[w] = (nxt, time.time())
                 nxt += 1
-                inflight += 1
-            msg = self._get()
-            if msg[0] == 'fail':
-                raise RuntimeError("job %d failed on worker %d (%s):\n%s" % (msg[2], msg[1], self.devices[msg[1]], msg[3]))
-            if msg[0] == 'done':
-                results[msg[2]] = msg[3]
-                idle.append(msg[1])
-                inflight -= 1
+            try:
+                msg = self._get(timeout=1.0 if job_timeout else None)
+            except TimeoutError:
+                msg = None
+            if msg is not None and msg[0] in ('done', 'fail') and msg[2] == rid:
+                w = msg[1]
+                started.pop(w, None)
+                idle.append(w)
+                if msg[0] == 'done':
+                    results[msg[3]] = msg[4]
+                elif failure is None:
+                    failure = "job %d failed on worker %d (%s):\n%s" % (msg[3], w, self.devices[w], msg[4])
+            if job_timeout:
+                for w, (idx, t0) in list(started.items()):
+                    if time.time() - t0 > job_timeout:
+                        self._respawn(w)
+                        started.pop(w)
+                        idle.append(w)
+                        if failure is None:
+                            failure = "job %d exceeded %.0f s on worker %d (%s); the worker was replaced" % (idx, job_timeout, w, self.devices[w])
+        if failure is not None:
+            raise RuntimeError(failure)
         return results
+
+    def _respawn(self, w):
+        """terminate worker w and start a fresh process in its place (it loses the datasets: they are re-sent)"""
+        p = self.procs[w]
+        if p.is_alive():
+            p.terminate()
+        p.join(timeout=10)
+        q = self._ctx.Queue()
+        q.cancel_join_thread()
+        np_ = self._ctx.Process(target=_worker, args=(w, self.devices[w], self._runner, q, self.outbox), daemon=True)
+        np_.start()
+        self.inboxes[w], self.procs[w] = q, np_
+        for key, (X, y) in self._datasets.items():
+            q.put(('dataset', key, X, y))
 
     def close(self):
         for q, p in zip(self.inboxes, self.procs):

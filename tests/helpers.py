@@ -114,6 +114,9 @@ def stub_training(job, datasets, device):
     val = float(np.mean(X[tr]) - np.mean(X[te]) + 0.01 * job.get('percentlabeled', 0) + np.mean(y[te]))
     if job.get('explode'):
         raise ValueError("stub failure requested")
+    if job.get('sleep'):
+        import time
+        time.sleep(job['sleep'])
     return (val, os.getpid(), device)
 
 

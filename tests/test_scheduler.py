@@ -55,6 +55,31 @@ def test_device_list_and_failure_report():
         RunScheduler(gpus=0)
 
 
+def test_scheduler_survives_a_failed_run_and_a_hung_job():
+    """After a failed run() the same scheduler must give correct results again (no stale 'done' message of the failed run may
+    land in the next run's result slots); a job that exceeds job_timeout has its worker replaced by a fresh process."""
+    from mr_gan_amd.scheduler import RunScheduler
+    rs = np.random.RandomState(3)
+    X, y = rs.randn(120, 5), rs.randint(0, 6, size=120)
+    with RunScheduler(runner=stub_training, devices=['cpu', 'cpu']) as sched:
+        key = sched.put_dataset(X, y)
+        jobs = _jobs(6, key)
+        want = [stub_training(j, {key: (X, y)}, 'cpu')[0] for j in jobs]
+        bad = [dict(j) for j in jobs]
+        bad[0]['explode'] = True
+        bad[1]['sleep'] = 1.0                                   # still in flight when job 0 fails
+        with pytest.raises(RuntimeError, match="stub failure requested"):
+            sched.run(bad)
+        out = sched.run(jobs)                                   # same workers, same dataset
+        np.testing.assert_allclose([o[0] for o in out], want, rtol=0, atol=0)
+        hung = [dict(j) for j in jobs[:3]]
+        hung[1]['sleep'] = 60.0
+        with pytest.raises(RuntimeError, match="exceeded"):
+            sched.run(hung, job_timeout=2.0)
+        out = sched.run(jobs)                                   # the replaced worker got the dataset again
+        np.testing.assert_allclose([o[0] for o in out], want, rtol=0, atol=0)
+
+
 def test_scheduled_table1_prints_the_reference_lines(capsys):
     """--gpus N routes table 1 through the scheduler and still prints the reference's lines in the reference's order."""
     import importlib
@@ -69,6 +94,7 @@ def test_scheduled_table1_prints_the_reference_lines(capsys):
 
         def run(self, jobs):
             self.batches.append(len(jobs))
+            self.jobs = getattr(self, 'jobs', []) + list(jobs)
             return [0.25 + 0.001 * j['percentlabeled'] for j in jobs]
 
         def __enter__(self):
@@ -97,3 +123,54 @@ def test_scheduled_table1_prints_the_reference_lines(capsys):
     i50 = out.index('Percentage of training data labeled: 50%')
     assert 'Test error: 0.3' in out[i50:i50 + 200]              # 0.25 + 0.001 * 50
     assert out.index('Force modality') < out.index('Temperature modality') < out.index('Force and Contact Mic modality')
+
+
+def test_scheduled_tables_3_5_6_dispatch_every_training(capsys):
+    """tables 3 (leave-one-object-out), 5 (contact time) and 6 (amount of unlabeled data) through the scheduler: the job counts
+    of mr_gan.py:267-282, :289-318, :324-341 and the reference's lines in the reference's order."""
+    import importlib
+    M = importlib.import_module('mr_gan_amd.mr_gan')
+
+    class FakeScheduler(object):
+        def __init__(self, gpus, jobs_per_gpu):
+            self.batches, self.jobs = [], []
+
+        def put_dataset(self, X, y):
+            return 0
+
+        def run(self, jobs):
+            self.batches.append(len(jobs))
+            self.jobs += list(jobs)
+            return [0.125 for _ in jobs]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    made = []
+
+    def factory(gpus, jobs_per_gpu):
+        made.append(FakeScheduler(gpus, jobs_per_gpu))
+        return made[-1]
+
+    rs = np.random.RandomState(0)
+
+    def fake_dataset(modalities=0, leaveObjectOut=False, **kw):
+        if leaveObjectOut:
+            return {'m%d_o%d' % (m, o): {'x': rs.randn(5, 4).tolist(), 'y': [m] * 5} for m in range(6) for o in range(3)}
+        return rs.randn(60, 4), np.arange(60) % 6
+
+    M.main(['--tables', '3', '5', '6', '--gpus', '1'], dataset_fn=fake_dataset, scheduler_factory=factory)
+    out = capsys.readouterr().out
+    f = made[0]
+    # table 3: 2 modalities x 5 label fractions x 18 objects ; table 5: (3 x 7 + 7) x 6 folds ; table 6: 2 x 7 x 6 folds
+    assert sum(f.batches) == 2 * 5 * 18 + 28 * 6 + 2 * 7 * 6
+    assert out.count('Average leave-one-object-out error:') == 10
+    assert out.count('Average error:') == 28 + 14
+    assert 'm0_o0 Test error: 0.125 Test accuracy: 0.875' in out
+    t6 = [j for j in f.jobs if j.get('percentunlabeled') is not None]
+    assert sorted({j['percentunlabeled'] for j in t6}) == [0, 4, 8, 16, 32, 64, 96] and all(j['percentlabeled'] == 4 for j in t6)
+    loo = [j for j in f.jobs if 'trainTestSets' in j]
+    assert len(loo) == 180 and loo[0]['trainTestSets'][1].shape == (5, 4) and loo[0]['trainTestSets'][0].shape == (85, 4)
