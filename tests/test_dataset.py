@@ -54,3 +54,37 @@ def test_log_mel_properties():
     centre = np.argmax(fb[:, int(round(3000 / (sr / 2048)))])
     assert abs(int(np.argmax(S.mean(axis=1))) - centre) <= 1    # energy lands in the 3 kHz band
     assert np.all(fb >= 0) and fb.shape == (128, 1025)
+
+
+def test_svm_baseline_and_its_tables(capsys):
+    """mr_svm (mr_svm.py:77-116): RBF SVC on the labeled subset, and the --tables 2 4 loops with the reference's lines."""
+    from mr_gan_amd.mr_svm import main, mr_svm
+    from mr_gan_amd import synthetic_mreo
+    from sklearn.svm import SVC
+    from sklearn import preprocessing
+    from sklearn.utils import shuffle
+    X, y, _ = synthetic_mreo(d=40, trials=20, sep=3.0)
+    tr = np.arange(len(y)) % 6 != 0
+    sets = [X[tr], X[~tr], y[tr], y[~tr]]
+    got = mr_svm(None, None, percentlabeled=2, trainTestSets=sets, seed=3)
+    # literal transcription of mr_svm.py:94-110 with the same shuffle state
+    sc = preprocessing.StandardScaler()
+    a, b = sc.fit_transform(sets[0]), sc.transform(sets[1])
+    a, ya = shuffle(a, sets[2], random_state=np.random.RandomState(3))
+    xl = np.concatenate([a[ya == j][:20] for j in range(6)])
+    yl = np.concatenate([[j] * 20 for j in range(6)])
+    want = 1.0 - SVC(kernel='rbf', C=1.0).fit(xl, yl).score(b, sets[3])
+    assert got == want and got < 0.5
+
+    rs = np.random.RandomState(0)
+
+    def fake_dataset(modalities=0, leaveObjectOut=False, **kw):
+        if leaveObjectOut:
+            return {'m%d_o%d' % (m, o): {'x': rs.randn(4, 3).tolist(), 'y': [m] * 4} for m in range(6) for o in range(2)}
+        return rs.randn(36, 3), np.arange(36) % 6
+    calls = []
+    main(['--tables', '2', '4'], dataset_fn=fake_dataset, fn=lambda X, y, **kw: calls.append(kw['percentlabeled']) or 0.25)
+    out = capsys.readouterr().out
+    assert len(calls) == 2 * 7 * 6 + 2 * 5 * 12
+    assert out.count('Average error: 0.25 Average accuracy: 0.75') == 14
+    assert out.count('Average leave-one-object-out error: 0.25') == 10 and 'm0_o0 Test error: 0.25 Test accuracy: 0.75' in out
