@@ -230,11 +230,11 @@ def main():
     cfg.rank, cfg.world = rank, world
     use_dp = world > 1 or args.force_dp
     cfg.flags = dp_flags(exact=not args.local_stats) if use_dp else (0 if args.no_graph else E.FLAG_GRAPH)
-    if args.ablate:
-        E.load_library().mrgan_debug_ablate(args.ablate)
     stream = torch.cuda.Stream(dev)
     with torch.cuda.stream(stream):
         eng = E.Engine(cfg, dev)
+        if args.ablate:
+            eng.debug_ablate(args.ablate)
         # identical initial weights on every rank
         rs = np.random.RandomState(7)
         for net in (E.NET_G, E.NET_D):

@@ -11,7 +11,8 @@
  * from mrgan_last_error() (thread-local).  Nothing throws across the ABI.  All pointers named *_dev are device
  * pointers (HBM); the caller owns inputs and outputs, the handle owns weights, optimiser state and workspace.
  * Calls are asynchronous on `stream` unless a host output pointer is passed (then the call synchronises the
- * stream before returning).  One handle per device; a handle is not thread-safe; no global state.
+ * stream before returning).  One handle per device; a handle is not thread-safe; no global state (tuning and the
+ * diagnostic switches of mrgan_debug.h are per handle; nothing reads the environment).
  * No torch types appear here: the Python host passes tensor.data_ptr() and the raw hipStream_t.
  */
 #ifndef MRGAN_ABI_H
@@ -118,8 +119,14 @@ int mrgan_pair_hint(mrgan_handle* h, int on);
 /* Launch-structure knobs of one handle (results stay within rounding; defaults are the measured best).  Call between
  * steps, never inside a captured pair. */
 enum {
-    MRGAN_TUNE_CHAIN = 0         /* 1 (default where the layer widths allow): the 256-wide tail D3..D5 + loss head of the
+    MRGAN_TUNE_CHAIN = 0,        /* 1 (default where the layer widths allow): the 256-wide tail D3..D5 + loss head of the
                                   * discriminator runs as row-block chain launches; 0: one launch per layer            */
+    MRGAN_TUNE_KC_CFG = 1,       /* forward / input-gradient tile: -1 (default) measured table; 0 64x128/3 stages,
+                                  * 1 128x128, 2 256x128, 3 256x256, 4 64x128 pipelined fragments, 5 64x128/2 stages  */
+    MRGAN_TUNE_KC_PIPE = 2,      /* 1: pipelined-fragment variant for launches with <= 1 tile per CU (default 0)       */
+    MRGAN_TUNE_KS_W8 = 3,        /* 1: 8-wave blocks in the grouped weight-gradient launch (default 0: 4 waves)        */
+    MRGAN_TUNE_KS_GROUP = 4,     /* 0: one launch per weight gradient instead of one grouped launch (default 1)        */
+    MRGAN_TUNE_PAIR_GEN = 5      /* 0: mrgan_train_pair runs the two generator forwards separately (default 1: as one) */
 };
 int mrgan_set_tuning(mrgan_handle* h, int knob, int value);
 
@@ -159,21 +166,6 @@ enum { MRGAN_PROF_NAME_LEN = 96 };
 int mrgan_profile_begin(mrgan_handle* h);
 int mrgan_profile_end(mrgan_handle* h, mrgan_stream stream, int max_kernels, char* names, float* ms, int32_t* launches,
                       double* flops, double* bytes, int* n_kernels);
-
-/* diagnostics used by the parity tests */
-int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t step, uint32_t row0, int rows, int cols,
-                      float* out_dev, mrgan_stream stream);
-int mrgan_debug_tr_probe(uint16_t* out1024_dev, mrgan_stream stream);
-/* timing experiments only (results become wrong): 2 = skip the GEMM epilogues, 4 = skip the GEMM main loops */
-int mrgan_debug_ablate(int bits);
-int mrgan_debug_buffer(mrgan_handle* h, int kind, int l, void** ptr_dev, int* rows_per_seg, int* ld, int* elem_size);
-/* average device time (us) of `reps` back-to-back launches of one bf16 product on scratch buffers:
- * op 0 forward (relu+noise+mask), 1 input-gradient (relu mask), 2 weight-gradient with `splits` slabs */
-int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, int reps, float* avg_us);
-/* raw GEMM entry for kernel-level parity tests: op 0 = Y = act(X W + b), 1 = dX = dY W^T, 2 = dW = X^T dY.
- * fp32 device buffers in and out (converted internally when dtype = bf16). */
-int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a_dev, const float* b_dev, const float* bias_dev,
-                     int act, int splits, float* out_dev, mrgan_stream stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/mrgan_abi.h"
+#include "../../include/mrgan_debug.h"
 #include "aux_kernels.h"
 #include "chain.h"
 #include "gemm.h"
@@ -24,7 +25,6 @@ int launch_tr_probe(unsigned short* out, hipStream_t s);
 namespace {
 
 thread_local std::string g_err;
-int g_ablate = 0;     // timing experiments (mrgan_debug_ablate)
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -113,7 +113,9 @@ struct mrgan_handle {
     float *cs_bn1, *cs_bn2, *cs_db[4], *cs_f, *cs_db3g, *cs_db2g, *cs_dbeta, *cs_dgamma, *db1g_part;
     float *head_part, *head_red, *loss_part; int head_stride, head_groups;
     int nblk_head, bnb_blocks;
-    bool chain_ok, use_chain; int chain_dbg;            // the 256-wide tail of the discriminator runs as row-block chain launches (gemm_chain.hip)
+    bool chain_ok, use_chain;            // the 256-wide tail of the discriminator runs as row-block chain launches (gemm_chain.hip)
+    int tune_kc_cfg, tune_bits, tune_pair_gen;      // mrgan_set_tuning
+    int ablate;                                      // mrgan_debug_ablate (timing experiments)
     AdamTile *tiles_g_dev, *tiles_d_dev; int ntiles_g, ntiles_d;
 
     // per-launch hipEvent profiling (bench.py's live roofline measurement)
@@ -291,7 +293,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->db1g_part = a.take<float>((size_t)h->bnb_blocks * N1p);
     // the tail D3..D5 + head as chain launches: bf16, A image <= 512 columns, outputs <= 256 columns
     h->chain_ok = h->bf16 && h->d[2].Kp <= CH_KMAX && h->d[2].Np <= CH_PW && h->d[3].Np <= CH_PW && h->d[4].Np <= CH_PW;
-    h->use_chain = h->chain_ok; h->chain_dbg = 0;
+    h->use_chain = h->chain_ok;
     h->nblk_head = 3 * ceil_div(B, HEAD_ROWS);                            // capacity; the chain path fills 3 * ceil(B / 64) of them
     h->head_stride = (int)round_up(h->Fp * KMAX + KMAX + h->Fp, 64);      // dW6 | db6 | bias grad of the feature layer
     h->head_groups = std::min(8, 3 * ceil_div(B, CH_ROWS));
@@ -306,13 +308,11 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     for (int l = 0; l < 5; ++l) {
         Dense& L = h->d[l];
         L.splits = choose_splits(tiles_d, 2 * S + B);
-        if (const char* e = getenv("MRGAN_DW_SPLITS_D")) L.splits = std::max(1, std::min(atoi(e), MAX_SLABS));
         L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     for (int l = 0; l < 3; ++l) {
         Dense& L = h->g[l];
         L.splits = choose_splits(tiles_g, B);
-        if (const char* e = getenv("MRGAN_DW_SPLITS_G")) L.splits = std::max(1, std::min(atoi(e), MAX_SLABS));
         L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     // ---- fused-mode gradient sources ----------------------------------------------------------------
@@ -436,7 +436,7 @@ Epi base_epi(mrgan_handle* h) {
     e.seed = h->cfg.seed;
     e.row0 = (uint32_t)(h->cfg.rank * h->B);
     e.st = h->state + h->cur;
-    e.ablate = g_ablate;
+    e.ablate = h->ablate; e.tune_kc_cfg = h->tune_kc_cfg; e.tune_bits = h->tune_bits;
     e.seg_step = 1;
     return e;
 }
@@ -926,6 +926,17 @@ int eval_rows(mrgan_handle* h, const float* x, const int32_t* idx, long ld, cons
             HIPCHK(hipMemcpy2DAsync(logits_out + r0 * h->cfg.num_classes, sizeof(float) * h->cfg.num_classes, h->logits,
                                     sizeof(float) * KMAX, sizeof(float) * h->cfg.num_classes, rows, hipMemcpyDeviceToDevice, s));
     }
+    // The evaluation used the training activations as scratch and filled rows [0, 3S) of every layer input, i.e. also the
+    // padding rows B..S of each training segment.  The bf16 weight gradients reduce over all S rows of a segment (zero dY
+    // padding rows x FINITE X padding rows): a non-finite value left there by an evaluation input would turn into NaN
+    // gradients from then on (0 * NaN).  Ragged batches only: re-zero those rows.
+    if (h->B < h->S) {
+        for (int l = 0; l < 5; ++l)
+            for (int sg = 0; sg < (l == 0 ? 5 : 3); ++sg) {
+                char* p = (char*)h->xin[l] + ((size_t)sg * h->S + h->B) * h->d[l].Kp * h->es;
+                HIPCHK(hipMemsetAsync(p, 0, (size_t)(h->S - h->B) * h->d[l].Kp * h->es, s));
+            }
+    }
     return 0;
 }
 
@@ -991,6 +1002,7 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
     set_gen_view(h, 0);
     h->cur = 0; h->graph_ready = false; h->graph_exec = nullptr; h->prof = false;
     h->pair_gen = h->gen_ready = 0; h->pair_g = nullptr; h->real_staged = 0;
+    h->tune_kc_cfg = -1; h->tune_bits = 0; h->tune_pair_gen = 1; h->ablate = 0;
     if (init_kernel_attributes() != 0 || chain_init_attributes() != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "hipFuncSetAttribute failed"); }
 #define CREATE_CHK(x)                                           \
     do {                                                        \
@@ -1126,7 +1138,7 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
     // Both sub-steps of a pair use the same generator weights (the D sub-step does not touch them), so their two
     // generator forwards run as one two-segment pass inside the D sub-step when the G sub-step draws its z on the
     // device and no statistic exchange sits between the generator's layers.
-    static const int pair_env = []() { const char* e = getenv("MRGAN_PAIR_GEN"); return e ? atoi(e) : 1; }();
+    const int pair_env = h->tune_pair_gen;
     auto both = [&]() {
         h->pair_gen = (pair_env && !h->sync_stats && !g->z_dev) ? 1 : 0;
         h->pair_g = h->pair_gen ? g : nullptr;
@@ -1164,7 +1176,12 @@ int mrgan_set_tuning(mrgan_handle* h, int knob, int value) {
     if (!h) return fail(-1, "null handle");
     if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_ready = false; }   // launches change
     switch (knob) {
-        case MRGAN_TUNE_CHAIN: h->use_chain = value != 0 && h->chain_ok; h->chain_dbg = value >> 1; break;
+        case MRGAN_TUNE_CHAIN: h->use_chain = value != 0 && h->chain_ok; break;
+        case MRGAN_TUNE_KC_CFG: h->tune_kc_cfg = value; break;
+        case MRGAN_TUNE_KC_PIPE: h->tune_bits = (h->tune_bits & ~TUNE_BIT_KC_PIPE) | (value ? TUNE_BIT_KC_PIPE : 0); break;
+        case MRGAN_TUNE_KS_W8: h->tune_bits = (h->tune_bits & ~TUNE_BIT_KS_W8) | (value ? TUNE_BIT_KS_W8 : 0); break;
+        case MRGAN_TUNE_KS_GROUP: h->tune_bits = (h->tune_bits & ~TUNE_BIT_NO_KS_GROUP) | (value ? 0 : TUNE_BIT_NO_KS_GROUP); break;
+        case MRGAN_TUNE_PAIR_GEN: h->tune_pair_gen = value ? 1 : 0; break;
         default: return fail(-1, "unknown tuning knob %d", knob);
     }
     return 0;
@@ -1256,7 +1273,11 @@ int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t ste
     return 0;
 }
 
-int mrgan_debug_ablate(int bits) { g_ablate = bits; return 0; }
+int mrgan_debug_ablate(mrgan_handle* h, int bits) {
+    if (!h) return fail(-1, "null handle");
+    h->ablate = bits;
+    return 0;
+}
 
 // activation buffers of the discriminator for activation-level tests: kind 0 = xin[l] (noisy layer input), 1 = dpre[l]
 // (gradient w.r.t. the layer's pre-activation), 2 = features.  Elements are fp32 or bf16 (the handle's dtype), laid out
@@ -1276,7 +1297,7 @@ int mrgan_debug_buffer(mrgan_handle* h, int kind, int l, void** ptr, int* rows_p
 // Kernel-level timing of one bf16 product on scratch buffers (contents irrelevant): op 0 forward (relu + noise +
 // mask), 1 input-gradient (relu mask), 2 weight-gradient.  Returns the average device time of `reps` back-to-back
 // launches in microseconds (hipEvent pair around the whole run, so launch gaps are included).
-int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, int reps, float* avg_us) {
+int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, int reps, int ablate, int kc_cfg, float* avg_us) {
     if ((n % 64) || (k % 64) || !avg_us) return fail(-1, "debug_gemm_time: bad argument");
     const size_t rows = (size_t)m * nbatch;
     const bool is_dx = op == 1 || op >= 5;
@@ -1299,7 +1320,7 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
     memset(&g, 0, sizeof g);
     g.nbatch = nbatch; g.splits = 1; g.A = ta; g.B = tb;
     g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
-    g.e.st = st; g.e.out = to; g.e.ablate = g_ablate; g.e.seed = 1;
+    g.e.st = st; g.e.out = to; g.e.ablate = ablate; g.e.tune_kc_cfg = kc_cfg; g.e.seed = 1;
     int epi;
     if (op == 0 || op == 3 || op == 4) {       // 0: relu + noise + mask ; 3: relu + mask ; 4: plain relu
         epi = EPI_FWD; g.M = m; g.N = n; g.K = k; g.kchunk = k; g.a_bs = (long)m * k; g.a_si = k; g.a_sk = 1; g.b_sj = k; g.b_sk = 1;
@@ -1398,7 +1419,7 @@ int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a, con
     memset(&g, 0, sizeof g);
     g.nbatch = 1; g.splits = 1; g.A = ta; g.B = tb;
     g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
-    g.e.st = st; g.e.out = to;
+    g.e.st = st; g.e.out = to; g.e.tune_kc_cfg = -1;
     int epi;
     if (op == 0) {
         epi = EPI_FWD; g.M = m; g.N = n; g.K = k; g.kchunk = k; g.a_si = k; g.a_sk = 1;

@@ -39,6 +39,8 @@ struct Epi {
     float* slab; long slab_stride;              // SLAB: fp32 [split][rows][ldo]
     const DevState* st;
     int ablate;              // timing experiments only: 2 = skip the epilogue, 4 = skip the main loop (one branch each)
+    int tune_kc_cfg;         // forward / dX tile config forced by mrgan_set_tuning (-1 = measured table)
+    int tune_bits;           // TUNE_BIT_* of the handle
 };
 
 struct GemmArgs {
@@ -340,6 +342,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
     }
 }
 
+enum { TUNE_BIT_KC_PIPE = 1, TUNE_BIT_KS_W8 = 2, TUNE_BIT_NO_KS_GROUP = 4 };
 // up to KS_GROUP_MAX weight-gradient products launched as one grid (gemm_bf16.hip)
 constexpr int KS_GROUP_MAX = 6;
 // a fold of per-block partial rows that rides along in the grouped launch (the loss head's weight-gradient partials):

@@ -26,8 +26,6 @@
 // 128-row grid would not fill the chip).  KS: 128 x 128 x 64.
 // The weight-gradient product over ragged segments (batch not a multiple of 128) keeps a register-staged
 // kernel that can zero-fill arbitrary reduction rows.
-#include <stdlib.h>
-
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -592,19 +590,13 @@ __global__ void tr_probe_kernel(unsigned short* out) {
 }
 }  // namespace
 
-// tuning knobs (read once): MRGAN_KS_NS = ring depth of the weight-gradient kernel, MRGAN_KC_CFG = forward/dX tile config
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 // epilogue variants compiled for the bf16 path (anything else is a host-side error)
 // tile configs: 0 = 64x128 / 4 waves / 3 stages ; 1 = 128x128 / 4 waves / 2 stages ; 2 = 256x128 / 8 waves / 2 stages ;
 //               3 = 256x256 / 8 waves / 2 stages ; 4 = cfg 0 with pipelined fragments ; 5 = 64x128 / 4 waves / 2 stages
-//               (three blocks per CU).  MRGAN_KC_CFG forces one; default picks by grid size.
+//               (three blocks per CU).  mrgan_set_tuning(MRGAN_TUNE_KC_CFG) forces one; default picks by grid size.
 template <int EPI, int VAR>
 static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
-    static const int forced = env_int("MRGAN_KC_CFG", -1);
+    const int forced = g.e.tune_kc_cfg;
     int cfg = forced;
     if (cfg < 0) {
         // measured on MI355X (scripts/gemm_bench.py): bigger tiles win once they still give >= ~1.5 blocks per CU
@@ -626,9 +618,9 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
     }
     if (cfg == 1) return launch_kc<EPI, 128, 128, 2, 2, 2, VAR>(g, s);
     if (cfg == 5) return launch_kc<EPI, 64, 128, 2, 2, 2, VAR>(g, s);      // 48 KiB ring: three blocks per CU
-    // cfg 4 / MRGAN_KC_PIPE=1 (launches with at most one 64x128 tile per CU): pipelined fragments, 4-stage ring.
+    // cfg 4 / TUNE_BIT_KC_PIPE (launches with at most one 64x128 tile per CU): pipelined fragments, 4-stage ring.
     // Measured no faster than cfg 0 on MI355X -- these launches are bound by the L2 -> LDS fill, not by the LDS -> MFMA chain.
-    static const int pipe = env_int("MRGAN_KC_PIPE", 0);
+    const int pipe = g.e.tune_bits & TUNE_BIT_KC_PIPE;
     const int t64 = ceil_div(g.M, 64) * ceil_div(g.N, 128) * g.nbatch;
     if (cfg == 4 || (forced < 0 && pipe && t64 <= 256)) return launch_kc<EPI, 64, 128, 2, 2, 4, VAR, true>(g, s);
     return launch_kc<EPI, 64, 128, 2, 2, 3, VAR>(g, s);
@@ -660,8 +652,7 @@ static bool ks_dense_k(const GemmArgs& g) {
 // n weight-gradient products as one launch; returns 1 (nothing launched) when a problem does not fit the grouped kernel
 int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname, const FoldJob* fold) {
     if (n < 1 || n > KS_GROUP_MAX) return 1;
-    static const int enabled = env_int("MRGAN_KS_GROUP", 1);
-    if (!enabled) return 1;
+    if (gs[0].e.tune_bits & TUNE_BIT_NO_KS_GROUP) return 1;
     KsGroup grp;
     memset(&grp, 0, sizeof grp);
     grp.n = n;
@@ -681,15 +672,15 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
     // The loop is bound by the LDS: ds_read_b64_tr_b16 moves 512 B per wave-instruction, and 128x128 blocks of 8 waves
     // (64x32 per wave) need 1.5 of them per MFMA.  Four waves of 64x64 need 1.0, and with a 2-stage ring (64 KiB) two
     // such blocks share a CU, which keeps 8 waves per CU for latency hiding: grouped D products 63 -> ~45 us.
-    // MRGAN_KS_W8=1 selects the 8-wave / 3-stage blocks (one per CU) again.
+    // TUNE_BIT_KS_W8 selects the 8-wave / 3-stage blocks (one per CU) again.
     constexpr int STAGE = 2 * 64 * 256;
-    static const int w8 = env_int("MRGAN_KS_W8", 0);
-    static bool attr_done = false;
+    const int w8 = gs[0].e.tune_bits & TUNE_BIT_KS_W8;
+    static bool attr_done8 = false, attr_done = false;
     if (w8) {
         auto kern = gemm_bf16_ks_group_kernel<3, 2, 4>;
-        if (!attr_done) {
+        if (!attr_done8) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE) != hipSuccess) return -2;
-            attr_done = true;
+            attr_done8 = true;
         }
         MRGAN_LAUNCH(kern, dim3(total), dim3(512), 3 * STAGE, s, grp);
         if (kname) *kname = "gemm_bf16_ks_group_kernel<3, 2, 4>";
@@ -713,9 +704,7 @@ int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kna
                              (g.seg_rows >= g.seg_stride || g.K <= g.seg_rows) &&
                              (long)g.K * g.a_sk * 2 < (1L << 31) && (long)g.K * g.b_sk * 2 < (1L << 31);
         if (dense_k) {
-            // MRGAN_KS_CFG: 0 = 4 waves (64x64 each), 3-stage ring ; 1 = 8 waves (64x32 each), 3 stages ; 2 = 8 waves, 4 stages
-            static const int cfg = env_int("MRGAN_KS_CFG", 1);
-            r = cfg == 0 ? launch_ks_fast<3, 2, 2>(g, s) : cfg == 1 ? launch_ks_fast<3, 2, 4>(g, s) : launch_ks_fast<4, 2, 4>(g, s);
+            r = launch_ks_fast<3, 2, 4>(g, s);      // single product: 8 waves (64x32 each), 3-stage ring
         } else {
             dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, 128), g.nbatch * g.splits);
             MRGAN_LAUNCH(gemm_bf16_ks_kernel, grid, dim3(256), 0, s, g);

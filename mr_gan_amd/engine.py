@@ -18,7 +18,7 @@ NET_G, NET_D = 0, 1
 FLAG_SYNC_STATS, FLAG_FLAT_GRADS, FLAG_GRAPH = 1, 2, 4
 D_GEN, D_MAIN, D_ADAM = 0, 1, 2
 G_GEN, G_FEAT, G_BWD, G_TAIL, G_ADAM = 0, 1, 2, 3, 4
-TUNE_CHAIN = 0
+TUNE_CHAIN, TUNE_KC_CFG, TUNE_KC_PIPE, TUNE_KS_W8, TUNE_KS_GROUP, TUNE_PAIR_GEN = range(6)
 REGION_BN_STATS, REGION_FM_MOMENTS, REGION_BN_BWD, REGION_GRAD_D, REGION_GRAD_G, REGION_WORKSPACE = range(6)
 
 EXPORTS = [
@@ -291,6 +291,9 @@ class Engine(object):
         off = p.value - self.workspace.data_ptr()
         return self.workspace[off:off + n.value].view(torch.float32)
 
+    def debug_ablate(self, bits):
+        _check(self.lib.mrgan_debug_ablate(self.handle, int(bits)))
+
     def debug_buffer(self, kind, l, nseg=3):
         """activation buffer (0 xin[l], 1 dpre[l], 2 features) as a float32 tensor [nseg, S, ld] (a copy)"""
         p, rows, ld, es = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
@@ -330,7 +333,7 @@ def debug_tr_probe(device="cuda:0"):
     return out.cpu().numpy().astype(np.uint16).reshape(2, 64, 8)
 
 
-def debug_gemm_time(op, m, n, k, nbatch=1, splits=1, reps=50):
+def debug_gemm_time(op, m, n, k, nbatch=1, splits=1, reps=50, ablate=0, kc_cfg=-1):
     us = C.c_float()
-    _check(load_library().mrgan_debug_gemm_time(op, m, n, k, nbatch, splits, reps, C.byref(us)))
+    _check(load_library().mrgan_debug_gemm_time(op, m, n, k, nbatch, splits, reps, ablate, kc_cfg, C.byref(us)))
     return us.value

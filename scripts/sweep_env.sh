@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: bash scripts/sweep_env.sh "VAR=val VAR2=val" "..." ; runs the bench (graph mode) once per setting
-for cfg in "$@"; do
+for cfg in "$@"; do   # (the library no longer reads tuning from the environment: use Engine.set_tuning in a script)
   echo "== $cfg"
   env $cfg python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys

@@ -95,7 +95,8 @@ def test_tables_harness_format(capsys):
 
 # ---- C ABI surface ------------------------------------------------------------------------------------------
 def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "mrgan_abi.h")).read()
+    """every function declared in include/*.h (the drop-in boundary mrgan_abi.h and the diagnostics of mrgan_debug.h)"""
+    src = open(os.path.join(ROOT, "include", "mrgan_abi.h")).read() + open(os.path.join(ROOT, "include", "mrgan_debug.h")).read()
     return sorted(set(re.findall(r"\b(mrgan_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -107,6 +108,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(E.EXPORTS) == names
+    # the boundary header has no diagnostic entry point, and nothing in the library reads the environment
+    assert "mrgan_debug_" not in open(os.path.join(ROOT, "include", "mrgan_abi.h")).read()
+    for f in os.listdir(os.path.join(ROOT, "mr_gan_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "mr_gan_amd", "csrc", f)).read(), f
 
 
 def test_struct_layout_matches_header():
