@@ -191,6 +191,10 @@ def main():
                          "one-GPU batch-B step")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (see mrgan_debug_ablate)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="mrgan_set_tuning experiments, e.g. --tune 1=3 (MRGAN_TUNE_KC_CFG = 3); results stay within rounding")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
+                    help="N > 1: payload of the gradient all-reduces (bf16 halves the bytes; a labelled, different numerical path)")
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 phase protocol (no all-reduce) on one GPU")
     args = ap.parse_args()
 
@@ -235,6 +239,8 @@ def main():
         eng = E.Engine(cfg, dev)
         if args.ablate:
             eng.debug_ablate(args.ablate)
+        for kv in args.tune:
+            eng.set_tuning(*[int(v) for v in kv.split("=")])
         # identical initial weights on every rank
         rs = np.random.RandomState(7)
         for net in (E.NET_G, E.NET_D):
@@ -262,7 +268,7 @@ def main():
         dargs = E.Engine.disc_args(xld, lab_stream, Xd, None, idx_lab, idx_unl, stream_mode=1)
         gargs = E.Engine.gen_args(Xd, None, idx_unl2, stream_mode=1)
         eng.set_iterations(0, 0)
-        runner = DataParallel(EngineBackend(eng), exact=not args.local_stats) if use_dp else None
+        runner = DataParallel(EngineBackend(eng), exact=not args.local_stats, grad_dtype=None if args.grad_dtype == "f32" else args.grad_dtype) if use_dp else None
 
         def step():
             if runner is not None:
@@ -384,7 +390,7 @@ def main():
                                   if args.hidden else "BASELINE configs[1]", args.rows, D, B, args.labeled_per_class),
                    "global_batch": B * world, "rows_per_gpu": B, "parallelism": "dp%d" % world if world > 1 else "single",
                    "batch_statistics": ("local_stats (per shard)" if args.local_stats else "synced over ranks") if world > 1 else "n/a",
-                   "launch": "eager phases + RCCL all-reduce" if world > 1 else ("eager" if args.no_graph else "hipGraph replay")},
+                   "launch": "eager phases + RCCL all-reduce (%s gradients)" % args.grad_dtype if world > 1 else ("eager" if args.no_graph else "hipGraph replay")},
         "roofline": roofline,
         "train_metrics": {"mean_loss_lab": metrics[0] / args.steps, "mean_loss_unl": metrics[1] / args.steps,
                           "mean_train_err": metrics[2] / args.steps, "mean_loss_gen": metrics[3] / args.steps},

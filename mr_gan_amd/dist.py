@@ -51,15 +51,32 @@ class EngineBackend(PhaseBackend):
 
 
 class DataParallel(object):
-    def __init__(self, backend, exact=True, group=None):
+    """grad_dtype: None (default) all-reduces the flat gradient buffers in fp32 -- replicas then reproduce the one-GPU step up
+    to summation order; 'bf16' sends them as bfloat16 (half the bytes on the xGMI links: 2.5 MB instead of 5.1 MB for the
+    discriminator at D = 512; the four scalars at the tail stay fp32) at the price of an 8-bit mantissa per addend -- a
+    different, labelled numerical path.  The small statistic regions always travel in fp32."""
+
+    def __init__(self, backend, exact=True, group=None, grad_dtype=None):
         self.backend = backend
         self.exact = exact
         self.group = group
+        self.grad_dtype = grad_dtype
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def _allreduce(self, which):
-        if self.world > 1:
-            dist.all_reduce(self.backend.region(which), op=dist.ReduceOp.SUM, group=self.group)
+        if self.world <= 1:
+            return
+        r = self.backend.region(which)
+        if self.grad_dtype == 'bf16' and which in (E.REGION_GRAD_D, E.REGION_GRAD_G):
+            import torch
+            body, tail = r[:-4], r[-4:].clone()
+            g16 = body.to(torch.bfloat16)
+            dist.all_reduce(g16, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+            body.copy_(g16)
+            r[-4:].copy_(tail)
+        else:
+            dist.all_reduce(r, op=dist.ReduceOp.SUM, group=self.group)
 
     def disc_step(self, args):
         b = self.backend

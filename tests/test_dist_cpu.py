@@ -148,16 +148,27 @@ class OraclePhases(object):
             self.last = self.loss
 
 
-def _worker(rank, world, port, exact, q):
+def _case(sorted_labels=False):
+    case = Case(D=12, B=16, steps=2)
+    if sorted_labels:
+        # uneven label tiling: the tail of the reference's labeled stream only touches the first classes of the class-sorted
+        # pool (mr_gan.py:189), so the ranks of a sharded batch can see disjoint label sets
+        case.labels = np.sort(case.labels, axis=1)
+    return case
+
+
+def _worker(rank, world, port, exact, q, sorted_labels=False, grad_dtype=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mr_gan_amd.dist import DataParallel
     B, D, steps = 16, 12, 2
-    case = Case(D=D, B=B, steps=steps)
+    case = _case(sorted_labels)
     h = B // world
     backend = OraclePhases(case.g0, case.d0, world, exact)
-    dp = DataParallel(backend, exact=exact)
+    if grad_dtype:                                        # the stand-in's regions are fp64; bf16 needs an fp32 carrier
+        backend.regions = {k: v.float() for k, v in backend.regions.items()}
+    dp = DataParallel(backend, exact=exact, grad_dtype=grad_dtype)
     res = []
     it = 0
     for t in range(steps):
@@ -181,11 +192,11 @@ def _free_port():
     return p
 
 
-def _run(exact):
+def _run(exact, world=2, sorted_labels=False, grad_dtype=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, exact, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exact, q, sorted_labels, grad_dtype)) for r in range(world)]
     for p in procs:
         p.start()
     out = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
@@ -197,8 +208,7 @@ def _run(exact):
 
 def test_two_ranks_reproduce_full_batch_step():
     out = _run(exact=True)
-    case = Case(D=12, B=16, steps=2)
-    ref = case.run_oracle()
+    ref = _case().run_oracle()
     (_, res0, d0, g0), (_, res1, d1, g1) = out
     for t in range(2):
         np.testing.assert_allclose(res0[2 * t], ref['disc'][t], rtol=1e-9, atol=1e-12)
@@ -210,6 +220,39 @@ def test_two_ranks_reproduce_full_batch_step():
     for a, b, r in zip(g0, g1, ref['g']):
         np.testing.assert_array_equal(a, b)
         np.testing.assert_allclose(a, r, rtol=1e-6, atol=1e-10)
+
+
+def test_four_ranks_with_disjoint_label_sets_reproduce_full_batch_step():
+    """world 4, four rows per rank, labels sorted so that every rank holds different classes: the labeled loss is a mean over
+    the GLOBAL batch, so only the protocol's 1/B_global scaling and the gradient all-reduce make this equal the one-process step"""
+    out = _run(exact=True, world=4, sorted_labels=True)
+    ref = _case(True).run_oracle()
+    for t in range(2):
+        np.testing.assert_allclose(out[0][1][2 * t], ref['disc'][t], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(out[0][1][2 * t + 1], ref['gen'][t], rtol=1e-8, atol=1e-14)
+    for r in range(1, 4):
+        for a, b in zip(out[0][2] + out[0][3], out[r][2] + out[r][3]):
+            np.testing.assert_array_equal(a, b)
+    for a, r in zip(out[0][2], ref['d']):
+        np.testing.assert_allclose(a, r, rtol=1e-7, atol=1e-10)
+    for a, r in zip(out[0][3], ref['g']):
+        np.testing.assert_allclose(a, r, rtol=1e-6, atol=1e-10)
+
+
+def test_bf16_gradient_payload_keeps_replicas_identical():
+    """grad_dtype='bf16': half the bytes per gradient all-reduce; replicas still agree bit for bit (they all receive the same
+    reduced bf16 values) and the losses stay those of the full-batch step; the weights differ from the fp32 exchange at the
+    bf16 level (a labelled, different numerical path)"""
+    out = _run(exact=True, world=2, grad_dtype='bf16')
+    ref = _case().run_oracle()
+    (_, res0, d0, g0), (_, res1, d1, g1) = out
+    np.testing.assert_allclose(res0[0], ref['disc'][0], rtol=1e-5, atol=1e-7)        # first sub-step: weights still identical
+    for a, b in zip(d0 + g0, d1 + g1):
+        np.testing.assert_array_equal(a, b)
+    from tests.helpers import update_rel_err
+    case = _case()
+    errs = [update_rel_err(a, r, w0) for a, r, w0 in zip(d0, ref['d'], case.d0)]
+    assert max(errs) < 0.5 and max(errs) > 1e-6
 
 
 def test_local_statistics_mode_is_a_different_algorithm():
