@@ -23,6 +23,11 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
 int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a_dev, const float* b_dev, const float* bias_dev,
                      int act, int splits, float* out_dev, mrgan_stream stream);
 
+/* fp8 (OCP e4m3) forward product on the matrix cores, operands quantised from the fp32 inputs with per-tensor scales:
+ * out[m,n] = act((q(a * scale_a) q(b * scale_b)) / (scale_a scale_b) + bias).  reps > 0 also times `reps` launches. */
+int mrgan_debug_gemm_fp8(int m, int n, int k, const float* a_dev, const float* b_dev, const float* bias_dev, int act, float scale_a,
+                         float scale_b, float* out_dev, int reps, float* avg_us, mrgan_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

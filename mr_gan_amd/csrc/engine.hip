@@ -1384,6 +1384,47 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
     return 0;
 }
 
+// fp8 forward product (gemm_fp8.hip): out[m,n] = act((q(a * scale_a) q(b * scale_b)) / (scale_a scale_b) + bias), q = e4m3 RNE.
+// reps > 0: returns the average device time of `reps` launches in *avg_us instead of writing `out` through fp32.
+int mrgan_debug_gemm_fp8(int m, int n, int k, const float* a, const float* b, const float* bias, int act, float scale_a, float scale_b,
+                         float* out, int reps, float* avg_us, mrgan_stream stream) {
+    if ((n % 64) || (k % 128) || !a || !b) return fail(-1, "debug_gemm_fp8: n %% 64 == 0 and k %% 128 == 0 are required");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *ta = nullptr, *tb = nullptr;
+    __bf16* to = nullptr;
+    HIPCHK(hipMalloc((void**)&ta, (size_t)m * k));
+    HIPCHK(hipMalloc((void**)&tb, (size_t)n * k));
+    HIPCHK(hipMalloc((void**)&to, (size_t)m * n * 2));
+    CHK(launch_to_fp8(a, k, ta, k, m, k, m, k, scale_a, 0, s));
+    CHK(launch_to_fp8(b, n, tb, k, k, n, k, n, scale_b, 1, s));          // Bt[n][k] = b[k][n]
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.M = m; g.N = n; g.K = k; g.nbatch = 1; g.splits = 1; g.kchunk = k; g.tiles_m = ceil_div(m, 64);
+    g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
+    g.A = ta; g.a_si = k; g.a_sk = 1; g.B = tb; g.b_sj = k; g.b_sk = 1;
+    g.e.act = act; g.e.n_valid = n; g.e.bias = bias; g.e.out = to; g.e.ldo = n; g.e.acc_scale = 1.0f / (scale_a * scale_b);
+    g.e.tune_kc_cfg = -1;
+    int r = launch_gemm_fp8_fwd(g, s);
+    if (!r && reps > 0 && avg_us) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps && !r; ++i) r = launch_gemm_fp8_fwd(g, s);
+        HIPCHK(hipEventRecord(e1, s));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *avg_us = 1e3f * ms / (float)reps;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    if (!r && out) hipLaunchKernelGGL(to_f32_kernel<__bf16>, grid2d(m, n), dim3(256), 0, s, (const __bf16*)to, (long)n, out, (long)n, m, n);
+    hipStreamSynchronize(s);
+    hipFree(ta); hipFree(tb); hipFree(to);
+    if (r) return fail(r, "debug_gemm_fp8: launch failed (%d)", r);
+    return 0;
+}
+
 int mrgan_debug_tr_probe(uint16_t* out, mrgan_stream stream) {
     if (!out) return fail(-1, "null argument");
     CHK(launch_tr_probe(out, (hipStream_t)stream));

@@ -39,6 +39,7 @@ struct Epi {
     float* slab; long slab_stride;              // SLAB: fp32 [split][rows][ldo]
     const DevState* st;
     int ablate;              // timing experiments only: 2 = skip the epilogue, 4 = skip the main loop (one branch each)
+    float acc_scale;         // fp8 forward: 1 / (scale of A * scale of B), applied to the accumulator before the bias
     int tune_kc_cfg;         // forward / dX tile config forced by mrgan_set_tuning (-1 = measured table)
     int tune_bits;           // TUNE_BIT_* of the handle
 };
@@ -359,6 +360,9 @@ struct KsGroup {
 // kname (optional) receives the name of the kernel instantiation that was launched, spelled as rocprofv3 prints it
 int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
 int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
+int launch_gemm_fp8_fwd(const GemmArgs& g, hipStream_t s, const char** kname = nullptr);      // gemm_fp8.hip
+int launch_to_fp8(const float* src, long ld_src, unsigned char* dst, long ld_dst, int rows, int cols, int prow, int pcol, float scale,
+                  int transpose, hipStream_t s);
 int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname = nullptr,
                               const FoldJob* fold = nullptr);   // 1 = not applicable
 

@@ -602,8 +602,10 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         // measured on MI355X (scripts/gemm_bench.py): bigger tiles win once they still give >= ~1.5 blocks per CU
         const int t128 = ceil_div(g.M, 128) * ceil_div(g.N, 128) * g.nbatch;
         const int t256 = ceil_div(g.M, 256) * ceil_div(g.N, 256) * g.nbatch;
-        (void)t256;
         cfg = t128 >= 384 ? 1 : 0;
+        // long reductions with enough 256x256 tiles to fill the chip (the wide stack of BASELINE configs[4]: K = N = 4096):
+        // 128 flop per staged byte instead of 64 -- 1.37 vs 0.95 PFLOP/s measured at 24576 x 4096 x 4096 (scripts/fp8_bench.py)
+        if (g.K >= 2048 && t256 >= 256 && (g.N % 256) == 0) cfg = 3;
         // long reductions into a narrow output (D2 forward: K = 1024, N = 512): three 64x128 blocks per CU with a
         // 2-stage ring hide the k-loop latency better than two 128x128 blocks (20.7 vs 21.7 us)
         if (EPI == EPI_FWD && cfg == 1 && g.K >= 1024 && g.N <= 512) cfg = 5;

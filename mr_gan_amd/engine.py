@@ -26,7 +26,7 @@ EXPORTS = [
     "mrgan_num_tensors", "mrgan_tensor_shape", "mrgan_set_weights", "mrgan_get_weights", "mrgan_get_slot",
     "mrgan_set_slot", "mrgan_get_iterations", "mrgan_set_iterations", "mrgan_disc_step", "mrgan_gen_step",
     "mrgan_train_pair", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
-    "mrgan_pair_hint", "mrgan_set_tuning", "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time", "mrgan_debug_buffer",
+    "mrgan_pair_hint", "mrgan_set_tuning", "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time", "mrgan_debug_buffer", "mrgan_debug_gemm_fp8",
 ]
 PROF_NAME_LEN = 96
 
@@ -337,3 +337,14 @@ def debug_gemm_time(op, m, n, k, nbatch=1, splits=1, reps=50, ablate=0, kc_cfg=-
     us = C.c_float()
     _check(load_library().mrgan_debug_gemm_time(op, m, n, k, nbatch, splits, reps, ablate, kc_cfg, C.byref(us)))
     return us.value
+
+
+def debug_gemm_fp8(a, b, bias=None, act=0, scale_a=1.0, scale_b=1.0, reps=0):
+    """e4m3 forward product act((q(a sa) q(b sb)) / (sa sb) + bias) -> (fp32 [m, n] result, average us per launch if reps > 0)"""
+    m, k = a.shape
+    n = b.shape[1]
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    us = C.c_float()
+    _check(load_library().mrgan_debug_gemm_fp8(m, n, k, _ptr(a), _ptr(b), _ptr(bias), act, C.c_float(scale_a), C.c_float(scale_b), _ptr(out),
+                                               reps, C.byref(us), _stream()))
+    return out, us.value

@@ -22,7 +22,7 @@ for n, d in out.items():
     # gfx950: FETCH_SIZE under-reports wide coalesced streaming reads by exactly 2x (MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact
     d['hbm_bytes_per_launch'] = (2.0 * d.get('FETCH_SIZE_KB_per_launch', 0.0) + d.get('WRITE_SIZE_KB_per_launch', 0.0)) * 1024.0
 import subprocess
-commit = open('gpurun_out/.commit').read().strip() if __import__('os').path.exists('gpurun_out/.commit') else 'unknown'
+commit = __import__('os').environ.get('MRGAN_COMMIT', 'unknown')
 json.dump({'commit': commit, 'command': 'scripts/traffic.sh (two --pmc passes: FETCH_SIZE, WRITE_SIZE; bench.py --steps 10 --warmup 2 --profile-steps 2 --no-cpu-baseline --no-graph)', 'kernels': out}, open('gpurun_out/traffic.json', 'w'), indent=1, sort_keys=True)
 for n, d in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]:
     print('%-52s launches %4d  fetch %9.0f KB  write %9.0f KB  -> %.2f MB/launch' % (n[:52], d['launches'], d.get('FETCH_SIZE_KB_per_launch', 0), d.get('WRITE_SIZE_KB_per_launch', 0), d['hbm_bytes_per_launch'] / 1e6))

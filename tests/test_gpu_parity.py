@@ -76,6 +76,26 @@ def test_gemm_products(dtype, tol, m, n, k):
         assert rel_err(dw, x64.T @ dy64) < tol, splits
 
 
+@pytest.mark.parametrize("m,n,k", [(200, 192, 256), (1024, 512, 1024)])
+def test_fp8_forward_product_matches_e4m3_quantised_reference(m, n, k):
+    """gemm_fp8.hip (v_mfma_f32_32x32x16_fp8_fp8): the product of the e4m3-quantised operands, exactly -- the reference
+    quantises the same scaled fp32 inputs with torch.float8_e4m3fn (OCP, round to nearest even) and multiplies in fp64, so
+    what is left is fp32 accumulation and the bf16 rounding of the output.  Asymmetric operands, ragged M."""
+    from mr_gan_amd import engine as E
+    rng = np.random.default_rng(m + k)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    pow2 = lambda v: float(2.0 ** np.floor(np.log2(224.0 / np.abs(v).max())))        # per-tensor power-of-two scale, 2x headroom
+    sa, sb = pow2(x), pow2(w)
+    q = lambda v, sc: torch.from_numpy(v * np.float32(sc)).to(torch.float8_e4m3fn).to(torch.float64).numpy() / sc
+    for act, f in ((0, lambda v: v), (1, lambda v: np.maximum(v, 0))):
+        got, _ = E.debug_gemm_fp8(_t(x), _t(w), _t(b), act=act, scale_a=sa, scale_b=sb)
+        want = f(q(x, sa) @ q(w, sb) + b)
+        assert rel_err(got.cpu().numpy(), want) < 6e-3, act             # bf16 output rounding (2^-9 of the largest element)
+        assert rel_err(got.cpu().numpy(), f(x.astype(np.float64) @ w + b)) < 0.1     # and fp8 itself stays a ~3 % perturbation
+
+
 def test_device_noise_matches_restatement():
     eng = _engine(16, 52, 0)
     # the generator is integer arithmetic (hash -> bytes -> i8 MFMA with a +-1 Hadamard operand) up to one fp32 scale:
