@@ -107,6 +107,19 @@ int mrgan_disc_step(mrgan_handle* h, const mrgan_disc_args* a, int phase_first, 
 /* out1_host (optional): loss_gen */
 int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int phase_first, int phase_last,
                    float* out1_host, mrgan_stream stream);
+/* Supervised baseline on the same discriminator stack (mr_nn.py:101-118): one Keras train_on_batch of the 6-layer MLP with
+ * GaussianNoise, loss = mse against the one-hot label, Adam with the handle's lr / beta_1 (Keras defaults 0.001 / 0.9: set
+ * them in mrgan_config).  Uses the D network and its Adam slots only; one iteration counter step per call.  A handle should
+ * run either the GAN loop or this loop.  out2_host (optional): loss, training error of the batch.
+ * rows_valid (0 = batch): Keras' short last batch of an epoch -- the first rows_valid rows count (means over rows_valid),
+ * the remaining rows must be readable and carry label -1. */
+typedef struct mrgan_sup_args {
+    const float* x_dev; const int32_t* idx_dev; const int32_t* labels_dev;
+    int64_t ld_x;
+    int32_t stream_mode, rows_valid;
+} mrgan_sup_args;
+int mrgan_sup_step(mrgan_handle* h, const mrgan_sup_args* a, float* out2_host, mrgan_stream stream);
+
 /* one iteration of the hot loop (mr_gan.py:204-213): D step then G step */
 int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_args* g, mrgan_stream stream);
 /* For hosts that drive the phases themselves (data parallel) and know that the next mrgan_disc_step is followed by a

@@ -49,7 +49,8 @@ int launch_bn_bwd(int bf16, const BnBwdArgs& a, hipStream_t s);
 int stat_row_blocks(int rows);                                 // row blocks of the column-statistic kernels
 
 // ---- loss head (mr_gan.py:128, :146-149, :161-162): last dense + losses + their gradients ----
-enum { HEAD_LAB = 0, HEAD_UNL = 1, HEAD_FAKE = 2, HEAD_EVAL = 3, HEAD_LOGITS = 4 };
+enum { HEAD_LAB = 0, HEAD_UNL = 1, HEAD_FAKE = 2, HEAD_EVAL = 3, HEAD_LOGITS = 4,
+       HEAD_MSE = 5 };   // supervised baseline (mr_nn.py:112): mean squared error against the one-hot label
 struct HeadArgs {
     const void* f; long f_bs; int ldf;         // features [seg][rows][ldf]
     int rows, nseg, seg_kind[3];

@@ -311,7 +311,21 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) dl[c] = 0.f;
     if (rowvalid) {
-        if (kind == HEAD_LAB || kind == HEAD_EVAL) {
+        if (kind == HEAD_MSE) {
+            // Keras 'mse' on one-hot targets (mr_nn.py:99, :112): mean over the classes, then over the batch
+            const long lo = a.labels_stream ? (long)a.st->batch * a.rows : 0;
+            const int y = a.labels[lo + row];
+            err = (y >= 0 && am != y) ? 1.f : 0.f;
+            const float invc = 1.0f / (float)a.classes;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) {
+                if (c < a.classes && y >= 0) {            // label -1: padding row of a short last batch, no contribution
+                    const float d = l[c] - (c == y ? 1.f : 0.f);
+                    loss0 = fmaf(d * d, invc, loss0);
+                    dl[c] = 2.0f * d * invc * a.inv_count;
+                }
+            }
+        } else if (kind == HEAD_LAB || kind == HEAD_EVAL) {
             const long lo = a.labels_stream ? (long)a.st->batch * a.rows : 0;
             const int y = a.labels[lo + row];
             err = (am != y) ? 1.f : 0.f;

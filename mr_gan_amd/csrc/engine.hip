@@ -883,6 +883,49 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// supervised step of the NN baseline (mr_nn.py:101-118): the discriminator stack alone, one segment, mse head
+// ---------------------------------------------------------------------------------------------------
+int sup_step(mrgan_handle* h, const mrgan_sup_args* a, hipStream_t s) {
+    const int B = h->B;
+    prof_backlog(h, s);
+    StageArgs st;
+    memset(&st, 0, sizeof st);
+    data_seg(st.s[0], h, a->x_dev, a->idx_dev, a->ld_x, 0, 0, a->stream_mode);
+    st.nseg = 1;
+    stage_common(st, h, nullptr, 0, -1);
+    PROF("stage_kernel", launch_stage(h->bf16, st, s));
+    CHK(disc_fwd_train(h, 1, false, 0, s, 5));
+    HeadArgs hd;
+    memset(&hd, 0, sizeof hd);
+    hd.f = h->feat; hd.f_bs = (long)h->S * h->Fp; hd.ldf = h->Fp; hd.rows = B; hd.nseg = 1;
+    hd.seg_kind[0] = HEAD_MSE;
+    hd.feat = h->Fp; hd.feat_valid = h->F; hd.classes = h->cfg.num_classes;
+    hd.w = h->dt[10].p; hd.ldw = KMAX; hd.b = h->dt[11].p;
+    hd.labels = a->labels_dev; hd.st = h->state + h->cur; hd.labels_stream = a->stream_mode;
+    hd.inv_count = 1.0f / (float)(a->rows_valid > 0 ? a->rows_valid : B); hd.unl_weight = 0.f;
+    hd.logits = h->logits; hd.logits_bs = (long)h->S * KMAX;
+    hd.dpre = h->dpre[4]; hd.dpre_bs = (long)h->S * h->Fp; hd.ldd = h->Fp;
+    hd.part = h->head_part; hd.part_stride = h->head_stride; hd.off_db = h->Fp * KMAX; hd.off_dbf = h->Fp * KMAX + KMAX;
+    hd.loss_part = h->loss_part;
+    PROF("head_kernel", launch_head(h->bf16, hd, s));
+    for (int l = 4; l >= 1; --l)
+        CHK(dense_dx(h, h->d[l], h->dpre[l], B, 1, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1], nullptr,
+                     CS_SUM, h->cs_db[l - 1], nullptr, s));
+    DwJob jobs[5];
+    for (int l = 0; l < 5; ++l) jobs[l] = DwJob{&h->d[l], h->xin[l], h->dpre[l]};
+    const FoldJob fold = {h->head_part, h->head_red, (long)h->head_stride, ceil_div(B, HEAD_ROWS), h->head_stride, h->head_groups, 0};
+    CHK(dense_dw_all(h, jobs, 5, B, 1, s, &fold));
+    // (the bias / loss partial rows of the two other segments of the GAN step keep the zeros of mrgan_create)
+    const bool chain = h->use_chain;
+    h->use_chain = false;                                   // head_blocks(): the per-layer head wrote 32-row blocks
+    const int r = run_adam(h, MRGAN_NET_D, ADAM_FUSED, true, s, a->stream_mode ? 1 : 0);
+    h->use_chain = chain;
+    CHK(r);
+    h->cur ^= 1;
+    return 0;
+}
+
 int check_disc_args(const mrgan_handle* h, const mrgan_disc_args* a) {
     if (!a || !a->x_lab_dev || !a->x_unl_dev || !a->labels_dev) return fail(-2, "disc_step: x_lab, x_unl and labels are required");
     if (a->ld_x_lab < h->cfg.d_in || a->ld_x_unl < h->cfg.d_in) return fail(-2, "disc_step: row pitch smaller than d_in");
@@ -1124,6 +1167,25 @@ int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int p0, int p1, flo
     if (out1) {
         HIPCHK(hipMemcpyAsync(out1, h->step_out + 3, sizeof(float), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int mrgan_sup_step(mrgan_handle* h, const mrgan_sup_args* a, float* out2, mrgan_stream stream) {
+    if (!h || !a || !a->x_dev || !a->labels_dev) return fail(-1, "sup_step: x and labels are required");
+    if (a->ld_x < h->cfg.d_in) return fail(-2, "sup_step: row pitch smaller than d_in");
+    if (h->flat_grads || h->cfg.world != 1) return fail(-3, "sup_step: single-GPU handles only");
+    if (a->rows_valid < 0 || a->rows_valid > h->B) return fail(-2, "sup_step: rows_valid outside [0, batch]");
+    if (a->rows_valid && a->stream_mode) return fail(-2, "sup_step: a short batch cannot be combined with stream mode");
+    hipStream_t s = (hipStream_t)stream;
+    int r = sup_step(h, a, s);
+    if (r) return r;
+    if (out2) {
+        float o[3];
+        HIPCHK(hipMemcpyAsync(o, h->step_out, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const float k = a->rows_valid > 0 ? (float)h->B / (float)a->rows_valid : 1.f;     // the metrics pass divides by the batch
+        out2[0] = o[0] * k; out2[1] = o[2] * k;
     }
     return 0;
 }

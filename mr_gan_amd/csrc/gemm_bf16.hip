@@ -611,10 +611,12 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         if (EPI == EPI_FWD && cfg == 1 && g.K >= 1024 && g.N <= 512) cfg = 5;
     }
     if (cfg >= 2 && (g.N % 128) != 0) cfg = 0;
+    if (cfg == 6 && (g.N % 256) != 0) cfg = 1;
     // DX epilogues that may stage a tile of e.h in LDS (softplus derivative, xhat sums) only exist for the small tiles
     constexpr bool H_TILE = EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU;
     if (H_TILE && cfg >= 2) cfg = 1;
     if constexpr (!H_TILE) {
+        if (cfg == 6 && (g.N % 256) == 0) return launch_kc<EPI, 128, 256, 2, 4, 2, VAR>(g, s);      // 8 waves of 64x64
         if (cfg == 2) return launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
         if (cfg == 3) return (g.N % 256) == 0 ? launch_kc<EPI, 256, 256, 2, 4, 2, VAR>(g, s) : launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
     }

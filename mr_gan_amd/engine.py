@@ -25,7 +25,7 @@ EXPORTS = [
     "mrgan_default_config", "mrgan_workspace_bytes", "mrgan_create", "mrgan_destroy", "mrgan_last_error",
     "mrgan_num_tensors", "mrgan_tensor_shape", "mrgan_set_weights", "mrgan_get_weights", "mrgan_get_slot",
     "mrgan_set_slot", "mrgan_get_iterations", "mrgan_set_iterations", "mrgan_disc_step", "mrgan_gen_step",
-    "mrgan_train_pair", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
+    "mrgan_train_pair", "mrgan_sup_step", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
     "mrgan_pair_hint", "mrgan_set_tuning", "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time", "mrgan_debug_buffer", "mrgan_debug_gemm_fp8",
 ]
 PROF_NAME_LEN = 96
@@ -58,6 +58,14 @@ class GenArgs(C.Structure):
         ("x_unl", C.c_void_p), ("idx_unl", C.c_void_p), ("z", C.c_void_p),
         ("ld_x_unl", C.c_int64),
         ("stream_mode", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class SupArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("idx", C.c_void_p), ("labels", C.c_void_p),
+        ("ld_x", C.c_int64),
+        ("stream_mode", C.c_int32), ("rows_valid", C.c_int32),
     ]
 
 
@@ -237,6 +245,22 @@ class Engine(object):
         out = (C.c_float * 1)()
         _check(self.lib.mrgan_gen_step(self.handle, C.byref(args), first, last, out if want_outputs else None, _stream()))
         return out[0] if want_outputs else None
+
+    @staticmethod
+    def sup_args(x, labels, idx=None, stream_mode=0, rows_valid=0):
+        a = SupArgs()
+        a.x, a.idx, a.labels = _ptr(x), _ptr(idx), _ptr(labels)
+        a.ld_x = x.stride(0)
+        a.stream_mode = stream_mode
+        a.rows_valid = rows_valid
+        a._refs = (x, labels, idx)
+        return a
+
+    def sup_step(self, args, want_outputs=True):
+        """one supervised train_on_batch of the NN baseline (mr_nn.py:117) -> (mse loss, training error of the batch)"""
+        out = (C.c_float * 2)()
+        _check(self.lib.mrgan_sup_step(self.handle, C.byref(args), out if want_outputs else None, _stream()))
+        return tuple(out) if want_outputs else None
 
     def train_pair(self, dargs, gargs):
         _check(self.lib.mrgan_train_pair(self.handle, C.byref(dargs), C.byref(gargs), _stream()))

@@ -28,6 +28,7 @@ NUM_CLASSES = 6
 BN_EPS = 2e-5                               # mr_gan.py:112
 ADAM_LR, ADAM_B1, ADAM_B2, ADAM_EPS = 0.0006, 0.5, 0.999, 1e-8   # mr_gan.py:165 + Keras defaults
 UNLABELED_WEIGHT = 1.0                      # mr_gan.py:79
+NN_ADAM_LR, NN_ADAM_B1 = 0.001, 0.9         # mr_nn.py:112 optimizer='adam': Keras-2.0.9 defaults
 
 
 # ----------------------------------------------------------------------------------------
@@ -211,6 +212,18 @@ def disc_loss_grads(l_lab, labels, l_unl, l_fake, unlabeled_weight=UNLABELED_WEI
     return d_lab.astype(dt), d_unl.astype(dt), d_fake.astype(dt)
 
 
+def mse_loss_grad(logits, labels):
+    """Keras 'mse' (losses.py: K.mean(K.square(y_pred - y_true), axis=-1), then the batch mean) on the linear outputs against
+    np_utils.to_categorical(labels) (mr_nn.py:99, :112); accuracy metric = argmax match (mr_nn.py:118)."""
+    B, K = logits.shape
+    y = np.zeros_like(logits)
+    y[np.arange(B), labels] = 1.0
+    d = logits - y
+    loss = np.mean(d * d)
+    err = np.mean(np.argmax(logits, axis=1) != labels)
+    return loss, err, (2.0 / (B * K)) * d
+
+
 def fm_loss(f_fake, f_real):
     mom_gen = f_fake.mean(axis=0)
     mom_real = f_real.mean(axis=0)
@@ -260,10 +273,10 @@ class Adam(object):
 class MRGANOracle(object):
     """State = Keras shared variables (weights, Adam slots, iteration counter)."""
 
-    def __init__(self, g, d, sigmas=D_SIGMAS):
+    def __init__(self, g, d, sigmas=D_SIGMAS, **adam):
         self.g = [np.array(p) for p in g]
         self.d = [np.array(p) for p in d]
-        self.adam = Adam(self.g, self.d)
+        self.adam = Adam(self.g, self.d, **adam)
         self.sigmas = sigmas
 
     # train_batch_disc([1, x_lab, labels, x_unl, noise]) -> [loss_lab, loss_unl, train_err]
@@ -302,6 +315,19 @@ class MRGANOracle(object):
         self.adam.apply(self.g, grads, 'g')
         return loss
 
+    # NN baseline (mr_nn.py:101-118): model.fit == train_on_batch of the same stack, loss='mse' against the one-hot label,
+    # optimizer='adam' (Keras defaults: construct with lr=NN_ADAM_LR, b1=NN_ADAM_B1) -> [mse, training error]
+    def sup_grads(self, x, labels, noise):
+        logits, _, c = disc_forward(self.d, x, noise, self.sigmas)
+        loss, err, dl = mse_loss_grad(logits, labels)
+        grads, _ = disc_backward(self.d, c, dlogits=dl)
+        return (loss, err), grads, dict(logits=logits)
+
+    def sup_step(self, x, labels, noise):
+        out, grads, _ = self.sup_grads(x, labels, noise)
+        self.adam.apply(self.d, grads, 'd')
+        return out
+
     # test_batch([0, x, labels]) -> err   (noise layers are identity at phase 0)
     def predict_logits(self, x):
         return disc_forward(self.d, x, None)[0]
@@ -319,7 +345,6 @@ class MRGANOracle(object):
 #                     copies, z, the noisy layer inputs, h1 / BN(h1) / h2, every dpre / dX activation.  Batch
 #                     statistics, bias gradients and column sums come from the unrounded fp32 values, as on the device;
 #                     the 250x6 loss head uses the fp32 master W6.
-#   quantize='fp8'  : see Fp8Spec below (e4m3 forward operands, e5m2 gradients, per-tensor power-of-two scales).
 # ----------------------------------------------------------------------------------------
 def bf16_round(x):
     """round-to-nearest-even to bfloat16, returned in x's dtype"""
@@ -337,10 +362,10 @@ def _ident(x):
 class MRGANMirror(object):
     """train_batch_disc / train_batch_gen in the engine's dataflow.  Same call signatures as MRGANOracle."""
 
-    def __init__(self, g, d, quantize=None, sigmas=D_SIGMAS, unlabeled_weight=UNLABELED_WEIGHT):
+    def __init__(self, g, d, quantize=None, sigmas=D_SIGMAS, unlabeled_weight=UNLABELED_WEIGHT, **adam):
         self.g = [np.array(p) for p in g]
         self.d = [np.array(p) for p in d]
-        self.adam = Adam(self.g, self.d)
+        self.adam = Adam(self.g, self.d, **adam)
         self.sigmas = sigmas
         self.uw = unlabeled_weight
         self.quantize = quantize
@@ -421,6 +446,31 @@ class MRGANMirror(object):
 
     def disc_step(self, *a, **k):
         out, grads, _ = self.disc_grads(*a, **k)
+        self.adam.apply(self.d, grads, 'd')
+        return out
+
+    # supervised step of the NN baseline in the engine's dataflow (engine.hip sup_step)
+    def sup_grads(self, x, labels, noise):
+        q = self.q
+        nl = len(self.d) // 2
+        c = self._disc_fwd(self._stage(x, noise[0]), noise)
+        W6, b6 = self.d[-2], self.d[-1]
+        logits = c['feat_q'] @ W6 + b6
+        loss, err, dl = mse_loss_grad(logits, labels)
+        grads = [np.zeros_like(p) for p in self.d]
+        grads[-2] = c['feat_q'].T @ dl
+        grads[-1] = dl.sum(axis=0)
+        dp = (dl @ W6.T) * (c['feat_q'] > 0)
+        grads[2 * (nl - 2) + 1] = dp.sum(axis=0)
+        dpre, db = self._disc_bwd(c, q(dp), True)
+        for l in range(nl - 1):
+            grads[2 * l] = c['xin'][l].T @ dpre[l]
+            if l < nl - 2:
+                grads[2 * l + 1] = db[l]
+        return (loss, err), grads, dict(logits=logits)
+
+    def sup_step(self, x, labels, noise):
+        out, grads, _ = self.sup_grads(x, labels, noise)
         self.adam.apply(self.d, grads, 'd')
         return out
 

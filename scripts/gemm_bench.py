@@ -7,6 +7,9 @@ from mr_gan_amd import engine as E
 
 B = 4096
 SHAPES = [  # (name, op, m, n, k, nbatch, splits)
+    ("fwd D1 2Bx512->1024", 0, B, 1024, 512, 2, 1),
+    ("fwd D2 2Bx1024->512", 0, B, 512, 1024, 2, 1),
+    ("fwd G3 2Bx512->512", 0, B, 512, 512, 2, 1),
     ("fwd D1 3Bx512->1024", 0, B, 1024, 512, 3, 1),
     ("fwd D1 relu+mask only", 3, B, 1024, 512, 3, 1),
     ("fwd D1 plain relu", 4, B, 1024, 512, 3, 1),

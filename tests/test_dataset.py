@@ -88,3 +88,19 @@ def test_svm_baseline_and_its_tables(capsys):
     assert len(calls) == 2 * 7 * 6 + 2 * 5 * 12
     assert out.count('Average error: 0.25 Average accuracy: 0.75') == 14
     assert out.count('Average leave-one-object-out error: 0.25') == 10 and 'm0_o0 Test error: 0.25 Test accuracy: 0.75' in out
+
+
+def test_nn_baseline_tables_run_the_reference_loops(capsys):
+    """mr_nn --tables 2 4 (mr_nn.py:128-168): the same loops and lines as mr_svm's, around the HIP-engine mr_nn()"""
+    from mr_gan_amd.mr_nn import main
+    rs = np.random.RandomState(0)
+
+    def fake_dataset(modalities=0, leaveObjectOut=False, **kw):
+        if leaveObjectOut:
+            return {'m%d_o%d' % (m, o): {'x': rs.randn(4, 3).tolist(), 'y': [m] * 4} for m in range(6) for o in range(2)}
+        return rs.randn(36, 3), np.arange(36) % 6
+    calls = []
+    main(['--tables', '4'], dataset_fn=fake_dataset, fn=lambda X, y, **kw: calls.append(kw['percentlabeled']) or 0.5)
+    out = capsys.readouterr().out
+    assert calls == [p for _ in range(2) for p in (1, 4, 16, 50, 100) for _ in range(12)]
+    assert out.count('Average leave-one-object-out error: 0.5') == 10

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import mrgan_oracle as O
-from tests.helpers import SEED, Case, cosine, frob_rel_err, rel_err, update_rel_err
+from tests.helpers import SEED, Case, cosine, frob_rel_err, noise_set, rel_err, update_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -188,6 +188,61 @@ def test_fp32_gradients_match_oracle():
         assert rel_err(a, b) < 2e-4, ("dG", i)          # measured ~1e-5 on db1 (cancellation), ~1e-6 elsewhere
     assert abs(eng.gen_step(ga, E.G_ADAM, E.G_ADAM) - loss) < 2e-3 * abs(loss) + 1e-9
     eng.close()
+
+
+@pytest.mark.parametrize("dtype,D,B,short", [(0, 48, 20, 0), (0, 400, 20, 7), (1, 400, 20, 0), (1, 72, 50, 33)])
+def test_supervised_steps_match_oracle(dtype, D, B, short):
+    """mrgan_sup_step = one train_on_batch of the NN baseline (mr_nn.py:101-118).  fp32 against the fp64 restatement, bf16
+    against the bf16 mirror (tolerance rule of test_bf16_steps_match_bf16_mirror); `short` = Keras' short last batch."""
+    from mr_gan_amd import engine as E
+    case = Case(D=D, B=B, steps=3)
+    kw = dict(lr=O.NN_ADAM_LR, b1=O.NN_ADAM_B1)
+    ref = O.MRGANOracle(case.g0, case.d0, **kw)
+    mir = O.MRGANMirror(case.g0, case.d0, quantize='bf16' if dtype else None, **kw)
+    cfg = E.default_config(D, B)
+    cfg.dtype, cfg.seed, cfg.lr, cfg.beta1 = dtype, SEED, O.NN_ADAM_LR, O.NN_ADAM_B1
+    eng = E.Engine(cfg, DEV)
+    _load(eng, case)
+    for t in range(case.steps):
+        n = short if (short and t == 1) else B
+        x, y = case.x_lab[t].astype(np.float64), case.labels[t]
+        noise = [m[:n] for m in noise_set(SEED, 0, t, B, D)]
+        yb = y.copy()
+        yb[n:] = -1
+        got = eng.sup_step(E.Engine.sup_args(_t(case.x_lab[t]), _t(yb, torch.int32), rows_valid=0 if n == B else n))
+        want, wm = ref.sup_step(x[:n], y[:n], noise), mir.sup_step(x[:n], y[:n], noise)
+        slack = 0.0 if t == 0 else 0.25
+        if dtype == 0:
+            assert abs(got[0] - want[0]) < (2e-4 + slack * 0.02) * want[0], (t, got, want)
+        else:
+            assert abs(got[0] - wm[0]) < max(3e-3, 0.6 * abs(wm[0] - want[0]) / want[0] + slack * 0.2) * want[0], (t, got, wm, want)
+        assert abs(got[1] - (want[1] if dtype == 0 else wm[1])) <= (1e-6 if t == 0 else 2.01 / n)
+    w = eng.get_weights(E.NET_D)
+    for i, (a, b, m, w0) in enumerate(zip(w, ref.d, mir.d, case.d0)):
+        if dtype == 0:
+            assert update_rel_err(a, b, w0) < 0.03, ("D", i, update_rel_err(a, b, w0))
+        else:
+            assert update_rel_err(a, m, w0) < max(0.05, 0.85 * update_rel_err(m, b, w0)), ("D", i, update_rel_err(a, m, w0), update_rel_err(m, b, w0))
+    assert eng.get_iterations() == case.steps
+    eng.close()
+
+
+def test_nn_baseline_fit_learns_planted_structure():
+    """MRNN.fit / evaluate (mr_nn.py:117-118) end to end on a separable problem, short last batch included"""
+    from mr_gan_amd.mr_nn import MRNN
+    rng = np.random.default_rng(5)
+    centers = rng.standard_normal((6, 40)) * 2.0
+    y = np.repeat(np.arange(6), 37).astype(np.int32)              # 222 rows: 11 batches of 20 + one of 2
+    x = (centers[y] + rng.standard_normal((len(y), 40))).astype(np.float32)
+    yt = np.repeat(np.arange(6), 50).astype(np.int32)
+    xt = (centers[yt] + rng.standard_normal((len(yt), 40))).astype(np.float32)
+    model = MRNN(40, seed=3)
+    before = model.evaluate(xt, yt)
+    hist = model.fit(x, y, epochs=15, rng=np.random.RandomState(1))
+    after = model.evaluate(xt, yt)
+    assert model.engine.get_iterations() == 15 * 12
+    assert before > 0.5 and after < 0.05 and hist[-1]['loss'] < 0.1, (before, after, hist)
+    model.engine.close()
 
 
 def test_device_z_matches_restatement():

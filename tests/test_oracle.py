@@ -228,3 +228,29 @@ def test_fp32_arithmetic_alone_moves_post_adam_logits_by_more_than_1e3():
     assert rel_err(r32['logits0'], r64['logits0']) < 1e-5
     e = rel_err(r32['logits'], r64['logits'])
     assert 1e-3 < e < 5e-2, e
+
+
+def test_supervised_step_grads_match_autograd_and_mirror():
+    """NN baseline (mr_nn.py:101-118): mse against the one-hot label through the noisy discriminator stack, Keras' default
+    Adam.  The closed-form gradients are pinned to autograd; the engine-dataflow mirror without rounding must equal them."""
+    g, d, x, labels, _, _, n1, _, _ = _rand_problem(D=30, B=20, seed=11)
+    a = O.MRGANOracle(g, d, lr=O.NN_ADAM_LR, b1=O.NN_ADAM_B1)
+    b = O.MRGANMirror(g, d, quantize=None, lr=O.NN_ADAM_LR, b1=O.NN_ADAM_B1)
+    (loss, err), grads, aux = a.sup_grads(x, labels, n1)
+    td = [_t(p) for p in d]
+    logits = _torch_disc(td, torch.tensor(x), n1)
+    onehot = torch.nn.functional.one_hot(torch.tensor(labels), 6).double()
+    tl = torch.nn.functional.mse_loss(logits, onehot)            # mean over classes and rows, as Keras' 'mse'
+    tl.backward()
+    assert abs(loss - tl.item()) < 1e-13
+    assert err == np.mean(logits.detach().numpy().argmax(1) != labels)
+    for u, v in zip(grads, td):
+        np.testing.assert_allclose(u, v.grad.numpy(), rtol=1e-9, atol=1e-13)
+    for _ in range(2):
+        oa, ob = a.sup_step(x, labels, n1), b.sup_step(x, labels, n1)
+        np.testing.assert_allclose(oa, ob, rtol=1e-12)
+    for u, v in zip(a.d, b.d):
+        np.testing.assert_allclose(u, v, rtol=1e-9, atol=1e-13)
+    # first Adam step of the Keras defaults moves every weight by lr (bias-corrected m / sqrt(v) = sign(g))
+    moved = np.abs(a.d[0] - d[0])
+    assert a.adam.iterations == 2 and moved.max() < 2.01 * O.NN_ADAM_LR
