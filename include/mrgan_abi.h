@@ -120,6 +120,14 @@ typedef struct mrgan_sup_args {
 } mrgan_sup_args;
 int mrgan_sup_step(mrgan_handle* h, const mrgan_sup_args* a, float* out2_host, mrgan_stream stream);
 
+/* Log-mel front end of the contact-microphone modality (mr_gan.py:42-47: librosa.feature.melspectrogram(y, sr, n_mels=128)
+ * followed by librosa.logamplitude(S, ref_power=np.max); n_fft 2048, hop 512, Slaney mel basis, -80 dB floor).  Stateless.
+ * y_dev: n_trials rows of n_samples float32 (pitch ld_y); out_dev: n_trials rows of n_mels * mrgan_logmel_frames(n_samples)
+ * float32, mel-major like log_S.flatten() (pitch ld_out). */
+int32_t mrgan_logmel_frames(int64_t n_samples);
+int mrgan_logmel(const float* y_dev, int64_t n_trials, int64_t n_samples, int64_t ld_y, int32_t sr, int32_t n_mels,
+                 float* out_dev, int64_t ld_out, mrgan_stream stream);
+
 /* one iteration of the hot loop (mr_gan.py:204-213): D step then G step */
 int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_args* g, mrgan_stream stream);
 /* For hosts that drive the phases themselves (data parallel) and know that the next mrgan_disc_step is followed by a

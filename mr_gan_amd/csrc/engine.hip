@@ -13,6 +13,7 @@
 #include "../../include/mrgan_debug.h"
 #include "aux_kernels.h"
 #include "chain.h"
+#include "logmel.h"
 #include "gemm.h"
 
 using namespace mrgan;
@@ -1169,6 +1170,16 @@ int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int p0, int p1, flo
         HIPCHK(hipStreamSynchronize(s));
     }
     return 0;
+}
+
+int32_t mrgan_logmel_frames(int64_t n_samples) { return n_samples > 0 ? logmel_frames((long)n_samples) : 0; }
+
+int mrgan_logmel(const float* y_dev, int64_t n_trials, int64_t n_samples, int64_t ld_y, int32_t sr, int32_t n_mels, float* out_dev,
+                 int64_t ld_out, mrgan_stream stream) {
+    const char* msg = "";
+    const int r = launch_logmel(y_dev, (long)n_trials, (long)n_samples, (long)ld_y, sr, n_mels, out_dev, (long)ld_out,
+                                (hipStream_t)stream, &msg);
+    return r ? fail(r, "%s", msg) : 0;
 }
 
 int mrgan_sup_step(mrgan_handle* h, const mrgan_sup_args* a, float* out2, mrgan_stream stream) {

@@ -25,7 +25,7 @@ EXPORTS = [
     "mrgan_default_config", "mrgan_workspace_bytes", "mrgan_create", "mrgan_destroy", "mrgan_last_error",
     "mrgan_num_tensors", "mrgan_tensor_shape", "mrgan_set_weights", "mrgan_get_weights", "mrgan_get_slot",
     "mrgan_set_slot", "mrgan_get_iterations", "mrgan_set_iterations", "mrgan_disc_step", "mrgan_gen_step",
-    "mrgan_train_pair", "mrgan_sup_step", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
+    "mrgan_train_pair", "mrgan_sup_step", "mrgan_logmel", "mrgan_logmel_frames", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
     "mrgan_pair_hint", "mrgan_set_tuning", "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time", "mrgan_debug_buffer", "mrgan_debug_gemm_fp8",
 ]
 PROF_NAME_LEN = 96

@@ -1,62 +1,51 @@
-"""Log-mel front end of the contact-microphone modality (mr_gan.py:42-47).
+"""Log-mel front end of the contact-microphone modality (mr_gan.py:42-47) on the GPU.
 
-The reference calls librosa 0.5.1 (`melspectrogram(y, sr=48000, n_mels=128)` then
-`logamplitude(S, ref_power=np.max)`); librosa is not installed here and cannot be fetched, so this is a
-numpy restatement of that version's published algorithm -- PARITY UNPINNED against librosa itself:
-  stft: n_fft 2048, hop 512, periodic Hann window, centred frames with reflect padding -> |X|^2
-  mel basis: Slaney scale (linear below 1 kHz, log above), fmin 0, fmax sr/2, area ("Slaney") normalisation
-  logamplitude: 10 log10(max(S, 1e-10)) - 10 log10(max(max S, 1e-10)), floored at max - 80 dB
-"""
+    S = librosa.feature.melspectrogram(contact, sr=48000, n_mels=128); log_S = librosa.logamplitude(S, ref_power=np.max)
+
+is one launch of logmel_kernel for ALL trials of a data set (mrgan_logmel, include/mrgan_abi.h; csrc/logmel.hip): a trial per
+workgroup, frames -> FFT -> power -> mel -> dB inside LDS.  There is no CPU path here; the numpy restatement used by the
+tests lives in oracle/melspec_oracle.py."""
+import ctypes as C
+
 import numpy as np
+import torch
+
+from mr_gan_amd import engine as E
 
 
-def _hz_to_mel(f):
-    f = np.asarray(f, dtype=np.float64)
-    f_sp = 200.0 / 3
-    mels = f / f_sp
-    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
-    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, mels)
+def logmel_frames(n_samples):
+    return int(E.load_library().mrgan_logmel_frames(C.c_int64(int(n_samples))))
 
 
-def _mel_to_hz(m):
-    m = np.asarray(m, dtype=np.float64)
-    f_sp = 200.0 / 3
-    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
-    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+def log_melspectrogram_device(y, sr=48000, n_mels=128):
+    """y: float32 device tensor [trials, samples] -> device tensor [trials, n_mels * frames] (log_S.flatten() per trial)"""
+    if not y.is_cuda or y.dtype != torch.float32 or y.dim() != 2 or y.stride(1) != 1:
+        raise ValueError("log_melspectrogram_device needs a float32 device matrix with contiguous rows")
+    lib = E.load_library()
+    frames = logmel_frames(y.shape[1])
+    out = torch.empty((y.shape[0], n_mels * frames), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = lib.mrgan_logmel(C.c_void_p(y.data_ptr()), C.c_int64(y.shape[0]), C.c_int64(y.shape[1]), C.c_int64(y.stride(0)),
+                              C.c_int32(int(sr)), C.c_int32(int(n_mels)), C.c_void_p(out.data_ptr()), C.c_int64(out.stride(0)),
+                              C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("mrgan_logmel failed (%d): %s" % (rc, lib.mrgan_last_error().decode()))
+    return out
 
 
-def mel_filterbank(sr, n_fft, n_mels=128, fmin=0.0, fmax=None):
-    fmax = sr / 2.0 if fmax is None else fmax
-    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
-    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
-    fdiff = np.diff(mel_f)
-    ramps = mel_f[:, None] - fftfreqs[None, :]
-    weights = np.zeros((n_mels, 1 + n_fft // 2))
-    for i in range(n_mels):
-        lower = -ramps[i] / fdiff[i]
-        upper = ramps[i + 2] / fdiff[i + 1]
-        weights[i] = np.maximum(0, np.minimum(lower, upper))
-    weights *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]        # Slaney area normalisation
-    return weights
-
-
-def power_stft(y, n_fft=2048, hop_length=512):
-    y = np.asarray(y, dtype=np.float64)
-    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)       # periodic Hann (fftbins=True)
-    ypad = np.pad(y, n_fft // 2, mode='reflect')
-    n_frames = 1 + (len(ypad) - n_fft) // hop_length
-    idx = np.arange(n_fft)[:, None] + hop_length * np.arange(n_frames)[None, :]
-    frames = ypad[idx] * window[:, None]
-    return np.abs(np.fft.rfft(frames, axis=0)) ** 2
-
-
-_BASIS = {}
-
-
-def log_melspectrogram(y, sr=48000, n_mels=128, n_fft=2048, hop_length=512, amin=1e-10, top_db=80.0):
-    key = (sr, n_fft, n_mels)
-    if key not in _BASIS:
-        _BASIS[key] = mel_filterbank(sr, n_fft, n_mels)
-    S = _BASIS[key] @ power_stft(y, n_fft, hop_length)
-    log_spec = 10.0 * np.log10(np.maximum(amin, S)) - 10.0 * np.log10(np.maximum(amin, S.max()))
-    return np.maximum(log_spec, log_spec.max() - top_db)
+def log_melspectrogram_batch(signals, sr=48000, n_mels=128, device='cuda:0', chunk=4096):
+    """signals: sequence of 1-D arrays (one per trial, lengths may differ) -> list of float32 vectors log_S.flatten()"""
+    if not torch.cuda.is_available():
+        raise RuntimeError("the log-mel front end runs on the GPU only (mrgan_logmel); no HIP device is visible")
+    out = [None] * len(signals)
+    by_len = {}
+    for i, s in enumerate(signals):
+        by_len.setdefault(len(s), []).append(i)
+    for n, idx in by_len.items():
+        for c0 in range(0, len(idx), chunk):
+            part = idx[c0:c0 + chunk]
+            host = np.stack([np.asarray(signals[i], dtype=np.float32) for i in part])
+            feats = log_melspectrogram_device(torch.from_numpy(host).to(device), sr, n_mels).cpu().numpy()
+            for k, i in enumerate(part):
+                out[i] = feats[k]
+    return out

@@ -66,17 +66,18 @@ def mr_gan(X, y, percentlabeled=50, percentunlabeled=None, epochs=100, trainTest
     return testerror
 
 
-def _logmel(contact, sr=48000, n_mels=128):
-    from mr_gan_amd.melspec import log_melspectrogram
-    return log_melspectrogram(np.asarray(contact, dtype=np.float64), sr=sr, n_mels=n_mels)
+def _logmel_all(contacts, sr=48000, n_mels=128):
+    """mr_gan.py:42-47 for every trial of the data set in one GPU launch per signal length (mr_gan_amd/melspec.py)"""
+    from mr_gan_amd.melspec import log_melspectrogram_batch
+    return log_melspectrogram_batch(contacts, sr=sr, n_mels=n_mels)
 
 
 def dataset(modalities=0, forcetempTime=4, contactmicTime=0.2, leaveObjectOut=False, verbose=False,
-            data_dir='data_processed'):
+            data_dir='data_processed', logmel_fn=_logmel_all):
     """mr_gan.py:23-71.  Reads the MREO pickles written by processdata.py (not shipped with the reference;
-    README.md:7-11) and concatenates the modality vectors in the reference's fixed order."""
-    X, y = [], []
-    objects = dict()
+    README.md:7-11) and concatenates the modality vectors in the reference's fixed order.  The log-mel spectrograms of the
+    contact-microphone modalities are computed for all trials at once on the GPU after the files are read."""
+    trials = []                                                  # (object name, material, temperature, force0, force1, contact)
     for m, material in enumerate(MATERIALS):
         if verbose:
             print('Processing', material)
@@ -85,29 +86,33 @@ def dataset(modalities=0, forcetempTime=4, contactmicTime=0.2, leaveObjectOut=Fa
         with open(fname, 'rb') as f:
             allData = pickle.load(f, encoding='latin1')          # py2 cPickle files (others/mr_nn_activation_map_py3.py:33)
         for objName, objData in allData.items():
-            if leaveObjectOut:
-                objects[objName] = {'x': [], 'y': []}
-                X = objects[objName]['x']
-                y = objects[objName]['y']
             for i in range(len(objData['temperature'])):
-                y.append(m)
-                if modalities > 2:
-                    log_S = _logmel(objData['contact'][i])       # mr_gan.py:42-47
-                f0, f1, temp = list(objData['force0'][i]), list(objData['force1'][i]), list(objData['temperature'][i])
-                if modalities == 0:
-                    X.append(f0 + f1)
-                elif modalities == 1:
-                    X.append(temp)
-                elif modalities == 2:
-                    X.append(temp + f0 + f1)
-                elif modalities == 3:
-                    X.append(log_S.flatten())
-                elif modalities == 4:
-                    X.append(temp + log_S.flatten().tolist())
-                elif modalities == 5:
-                    X.append(temp + f0 + f1 + log_S.flatten().tolist())
-                elif modalities == 6:
-                    X.append(f0 + f1 + log_S.flatten().tolist())
+                trials.append((objName, m, list(objData['temperature'][i]), list(objData['force0'][i]), list(objData['force1'][i]),
+                               objData['contact'][i] if modalities > 2 else None))
+    logs = logmel_fn([t[5] for t in trials]) if modalities > 2 else None     # mr_gan.py:42-47
+    X, y = [], []
+    objects = dict()
+    for n, (objName, m, temp, f0, f1, _) in enumerate(trials):
+        if leaveObjectOut:
+            if objName not in objects:
+                objects[objName] = {'x': [], 'y': []}
+            X, y = objects[objName]['x'], objects[objName]['y']
+        y.append(m)
+        log_S = logs[n] if logs is not None else None
+        if modalities == 0:
+            X.append(f0 + f1)
+        elif modalities == 1:
+            X.append(temp)
+        elif modalities == 2:
+            X.append(temp + f0 + f1)
+        elif modalities == 3:
+            X.append(log_S.flatten())
+        elif modalities == 4:
+            X.append(temp + log_S.flatten().tolist())
+        elif modalities == 5:
+            X.append(temp + f0 + f1 + log_S.flatten().tolist())
+        elif modalities == 6:
+            X.append(f0 + f1 + log_S.flatten().tolist())
     if leaveObjectOut:
         return objects
     X = np.array(X)

@@ -245,6 +245,38 @@ def test_nn_baseline_fit_learns_planted_structure():
     model.engine.close()
 
 
+def test_logmel_kernel_matches_numpy_restatement():
+    """mrgan_logmel (csrc/logmel.hip) against oracle/melspec_oracle.py (fp64 numpy restatement of librosa 0.5.1's
+    melspectrogram + logamplitude, mr_gan.py:42-47; parity unpinned against librosa itself).  fp32 FFT vs fp64: the values
+    are dB relative to the trial maximum with an 80 dB floor, tolerance 0.02 dB."""
+    from mr_gan_amd.melspec import log_melspectrogram_batch, log_melspectrogram_device, logmel_frames
+    from oracle.melspec_oracle import log_melspectrogram
+    rng = np.random.default_rng(0)
+    sr, n = 48000, 9600
+    t = np.arange(n) / sr
+    sigs = [np.sin(2 * np.pi * 3000 * t),                                             # pure tone: most bands at the floor
+            rng.standard_normal(n),                                                   # white noise
+            0.01 * rng.standard_normal(n) + np.sin(2 * np.pi * 440 * t) * np.exp(-t * 30),      # decaying tap + noise floor
+            np.cumsum(rng.standard_normal(n)) * 1e-3,                                 # red noise, large dynamic range
+            np.zeros(n)]                                                              # silence: everything at amin
+    sigs += [rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 1) for _ in range(59)]
+    assert logmel_frames(n) == 19
+    got = log_melspectrogram_device(_t(np.stack(sigs)), sr=sr, n_mels=128).cpu().numpy()
+    assert got.shape == (64, 128 * 19)
+    for i, s in enumerate(sigs):
+        want = log_melspectrogram(np.asarray(s, np.float32).astype(np.float64), sr=sr).flatten()
+        assert np.abs(got[i] - want).max() < 0.02, (i, np.abs(got[i] - want).max())
+        assert got[i].max() == 0.0 and got[i].min() >= -80.0
+    # ragged trial lengths, another mel count and sample rate, and the reference's argument checks
+    mixed = [rng.standard_normal(m) for m in (9600, 4800, 9600, 2049, 4800)]
+    outs = log_melspectrogram_batch(mixed, sr=44100, n_mels=40)
+    for s, o in zip(mixed, outs):
+        want = log_melspectrogram(np.asarray(s, np.float32).astype(np.float64), sr=44100, n_mels=40).flatten()
+        assert o.shape == want.shape and np.abs(o - want).max() < 0.02
+    with pytest.raises(RuntimeError, match="more than 1024 samples"):
+        log_melspectrogram_device(_t(rng.standard_normal((2, 1024))))
+
+
 def test_device_z_matches_restatement():
     case = Case(D=16, B=52, steps=2, device_z=True)
     ref = case.run_oracle()
