@@ -28,7 +28,10 @@ extern "C" {
 typedef struct mrgan_handle mrgan_handle;
 typedef void* mrgan_stream;               /* hipStream_t */
 
-enum { MRGAN_F32 = 0, MRGAN_BF16 = 1 };   /* arithmetic of the dense stacks: fp32 MFMA (parity) / bf16 MFMA (speed) */
+/* arithmetic of the dense stacks: fp32 MFMA (parity) / bf16 MFMA (speed) / fp8: the discriminator's dense products on
+ * the fp8 matrix cores (e4m3 activations and weights, e5m2 gradients, fp32 accumulate, delayed per-tensor power-of-two
+ * scales; the generator, the loss head and evaluation stay bf16; every padded width becomes a multiple of 128) */
+enum { MRGAN_F32 = 0, MRGAN_BF16 = 1, MRGAN_FP8 = 2 };
 enum { MRGAN_NET_G = 0, MRGAN_NET_D = 1 };
 enum {
     MRGAN_FLAG_SYNC_STATS = 1,   /* batch statistics (BN, feature-matching moments) are exchanged between phases   */
@@ -45,7 +48,7 @@ typedef struct mrgan_config {
     int32_t g_hidden[2];      /* 500, 500                                                  (mr_gan.py:111-113) */
     int32_t d_hidden[5];      /* 1000, 500, 250, 250, 250                                  (mr_gan.py:119-127) */
     int32_t num_classes;      /* 6 materials; the fake class is the implicit zero logit        (mr_gan.py:128) */
-    int32_t dtype;            /* MRGAN_F32 | MRGAN_BF16 */
+    int32_t dtype;            /* MRGAN_F32 | MRGAN_BF16 | MRGAN_FP8 */
     float sigma[5];           /* GaussianNoise std before discriminator dense 1..5: .3 .5 .5 .5 .5 (:118-126)  */
     float lr, beta1, beta2, adam_eps;      /* Adam(lr=0.0006, beta_1=0.5), Keras defaults         (mr_gan.py:165) */
     float bn_eps;             /* 2e-5                                                          (mr_gan.py:112) */

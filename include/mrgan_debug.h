@@ -24,9 +24,10 @@ int mrgan_debug_gemm(int dtype, int op, int m, int n, int k, const float* a_dev,
                      int act, int splits, float* out_dev, mrgan_stream stream);
 
 /* fp8 (OCP e4m3) forward product on the matrix cores, operands quantised from the fp32 inputs with per-tensor scales:
- * out[m,n] = act((q(a * scale_a) q(b * scale_b)) / (scale_a scale_b) + bias).  reps > 0 also times `reps` launches. */
+ * out[m,n] = act((q(a * scale_a) q(b * scale_b)) / (scale_a scale_b) + bias).  reps > 0 also times `reps` launches.
+ * kc_cfg: -1 = the launcher's choice, 1 = 128x128 blocks, 3 = 256x256 blocks. */
 int mrgan_debug_gemm_fp8(int m, int n, int k, const float* a_dev, const float* b_dev, const float* bias_dev, int act, float scale_a,
-                         float scale_b, float* out_dev, int reps, float* avg_us, mrgan_stream stream);
+                         float scale_b, float* out_dev, int reps, float* avg_us, int kc_cfg, mrgan_stream stream);
 
 #ifdef __cplusplus
 }

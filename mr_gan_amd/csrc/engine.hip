@@ -46,7 +46,8 @@ int fail(int code, const char* fmt, ...) {
         if (r_ != 0) return r_ < -9 ? r_ : fail(r_, "launch failed (%d) at %s:%d", r_, __FILE__, __LINE__); \
     } while (0)
 
-constexpr int PADW = 64;       // every feature dimension is padded to a multiple of 64 (zero-filled)
+constexpr int PADW = 64;       // every feature dimension is padded to a multiple of 64 (zero-filled); 128 in the fp8 mode
+thread_local int g_padw = PADW;
 constexpr int SEG_ALIGN = 128; // segment row stride is a multiple of the GEMM block tile
 
 struct Tensor {                // one trainable tensor (padded fp32 master + Adam slots)
@@ -65,6 +66,13 @@ struct Dense {
 };
 
 struct ProfRec { int cat; hipEvent_t start, stop; double flops, bytes; };      // device-side begin / end of one kernel (MRGAN_LAUNCH)
+
+// fp8 scaling slots: kind 0 = D sub-step, 1 = G sub-step; X = activations (e4m3), G = gradients (e5m2), W = weights (e4m3)
+constexpr int FP8_NSLOT = 25, FP8_DRY_PASSES = 5;
+inline int slot_x(int kind, int l) { return kind * 10 + l; }
+inline int slot_g(int kind, int l) { return kind * 10 + 5 + l; }
+inline int slot_w(int l) { return 20 + l; }
+constexpr float FP8_TARGET_E4M3 = 224.0f, FP8_TARGET_E5M2 = 28672.0f;      // half the largest finite value: 2x headroom
 
 struct Arena {
     char* base = nullptr; size_t off = 0, cap = 0;
@@ -114,6 +122,11 @@ struct mrgan_handle {
     float *cs_bn1, *cs_bn2, *cs_db[4], *cs_f, *cs_db3g, *cs_db2g, *cs_dbeta, *cs_dgamma, *db1g_part;
     float *head_part, *head_red, *loss_part; int head_stride, head_groups;
     int nblk_head, bnb_blocks;
+    // fp8 mode (gemm_fp8.hip): fp8 copies of the discriminator's activations x8 / gradients g8 (row-major and transposed),
+    // of its weights, and the scaling slots (index fp8_slot())
+    bool fp8; int fp8_kind; int fp8_cal[2];
+    unsigned char *x8[5], *x8t[5], *g8[5], *g8t[5], *w8[5], *w8t[5];
+    Fp8Slot* slots; float* slot_targets; float* accum_save;
     bool chain_ok, use_chain;            // the 256-wide tail of the discriminator runs as row-block chain launches (gemm_chain.hip)
     int tune_kc_cfg, tune_bits, tune_pair_gen;      // mrgan_set_tuning
     int ablate;                                      // mrgan_debug_ablate (timing experiments)
@@ -172,7 +185,7 @@ inline dim3 grid2d(int prow, int pcol) { return dim3(ceil_div(pcol, 64), ceil_di
 // ------------------------------------------------------------------------------------------------
 // layout
 // ------------------------------------------------------------------------------------------------
-int pad64(int x) { return (int)round_up(x, PADW); }
+int pad64(int x) { return (int)round_up(x, g_padw); }
 
 constexpr int MAX_SLABS = 16;
 // Reduction splits (= fp32 slabs per tensor, summed by the Adam kernel) of the weight-gradient products of one
@@ -191,7 +204,7 @@ int dw_tiles(const Dense& L) { return ceil_div(L.Kp, 128) * ceil_div(L.Np, 128);
 int validate(const mrgan_config& c) {
     if (c.d_in < 1 || c.batch < 1) return fail(-1, "d_in and batch must be positive");
     if (c.num_classes < 2 || c.num_classes > KMAX) return fail(-1, "num_classes must be in [2,%d]", KMAX);
-    if (c.dtype != MRGAN_F32 && c.dtype != MRGAN_BF16) return fail(-1, "unknown dtype");
+    if (c.dtype != MRGAN_F32 && c.dtype != MRGAN_BF16 && c.dtype != MRGAN_FP8) return fail(-1, "unknown dtype");
     if (c.world < 1 || c.rank < 0 || c.rank >= c.world) return fail(-1, "bad rank/world");
     if (c.world > 1 && (c.batch % 4) != 0) return fail(-1, "data-parallel shards need batch %% 4 == 0 (noise row groups)");
     if (c.world > 1 && (c.flags & (MRGAN_FLAG_FLAT_GRADS)) == 0) return fail(-1, "world > 1 requires MRGAN_FLAG_FLAT_GRADS");
@@ -203,8 +216,10 @@ int validate(const mrgan_config& c) {
 // carve the workspace; with base == nullptr only computes the size
 int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     const mrgan_config& c = h->cfg;
-    h->bf16 = c.dtype == MRGAN_BF16;
+    h->fp8 = c.dtype == MRGAN_FP8;
+    h->bf16 = c.dtype == MRGAN_BF16 || h->fp8;            // the fp8 mode keeps the whole bf16 machinery (generator, head, evaluation)
     h->es = h->bf16 ? 2 : 4;
+    g_padw = h->fp8 ? 128 : PADW;
     h->sync_stats = (c.flags & MRGAN_FLAG_SYNC_STATS) != 0;
     h->flat_grads = (c.flags & MRGAN_FLAG_FLAT_GRADS) != 0;
     h->B = c.batch; h->S = (int)round_up(c.batch, SEG_ALIGN); h->tiles_m = ceil_div(c.batch, 64);   // 64-row column-sum partials
@@ -280,6 +295,15 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
         h->dpre[l] = act(3 * (size_t)S, h->d[l].Np);
     }
     h->feat = act(3 * (size_t)S, h->Fp);
+    if (h->fp8) {
+        for (int l = 0; l < 5; ++l) {
+            const Dense& L = h->d[l];
+            h->x8[l] = a.take<unsigned char>(3 * (size_t)S * L.Kp); h->x8t[l] = a.take<unsigned char>(3 * (size_t)S * L.Kp);
+            h->g8[l] = a.take<unsigned char>(3 * (size_t)S * L.Np); h->g8t[l] = a.take<unsigned char>(3 * (size_t)S * L.Np);
+            h->w8[l] = a.take<unsigned char>((size_t)L.Kp * L.Np); h->w8t[l] = a.take<unsigned char>((size_t)L.Kp * L.Np);
+        }
+        h->slots = a.take<Fp8Slot>(FP8_NSLOT); h->slot_targets = a.take<float>(FP8_NSLOT); h->accum_save = a.take<float>(4);
+    }
     h->dxfake = act(S, h->Dp); h->dpre2g = act(S, h->g[1].Np); h->dhbn = act(S, N1p); h->dpre1g = act(S, N1p);
     h->logits = a.take<float>(3 * (size_t)S * KMAX);
 
@@ -293,7 +317,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->bnb_blocks = stat_row_blocks(B);
     h->db1g_part = a.take<float>((size_t)h->bnb_blocks * N1p);
     // the tail D3..D5 + head as chain launches: bf16, A image <= 512 columns, outputs <= 256 columns
-    h->chain_ok = h->bf16 && h->d[2].Kp <= CH_KMAX && h->d[2].Np <= CH_PW && h->d[3].Np <= CH_PW && h->d[4].Np <= CH_PW;
+    h->chain_ok = h->bf16 && !h->fp8 && h->d[2].Kp <= CH_KMAX && h->d[2].Np <= CH_PW && h->d[3].Np <= CH_PW && h->d[4].Np <= CH_PW;
     h->use_chain = h->chain_ok;
     h->nblk_head = 3 * ceil_div(B, HEAD_ROWS);                            // capacity; the chain path fills 3 * ceil(B / 64) of them
     h->head_stride = (int)round_up(h->Fp * KMAX + KMAX + h->Fp, 64);      // dW6 | db6 | bias grad of the feature layer
@@ -308,7 +332,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     for (int l = 0; l < 3; ++l) tiles_g += dw_tiles(h->g[l]);
     for (int l = 0; l < 5; ++l) {
         Dense& L = h->d[l];
-        L.splits = choose_splits(tiles_d, 2 * S + B);
+        L.splits = h->fp8 ? 1 : choose_splits(tiles_d, 2 * S + B);      // fp8: one product over all 3 S rows, no slabs to sum
         L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     for (int l = 0; l < 3; ++l) {
@@ -527,6 +551,129 @@ int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, 
 }
 
 void* rowptr(mrgan_handle* h, void* base, long row, int ld) { return (char*)base + (size_t)row * ld * h->es; }
+
+// ---------------------------------------------------------------------------------------------------
+// fp8 mode: the discriminator's dense products on gemm_fp8.hip.  Activations / gradients live as fp8 copies x8[l] / g8[l]
+// ([3][S][width], written by the producing product's epilogue) and, when the sub-step computes weight gradients, their
+// transposes x8t[l] / g8t[l] ([width][3 S]); weights as w8 [K][N] and w8t [N][K], refreshed after the D sub-step's Adam.
+// ---------------------------------------------------------------------------------------------------
+int run_gemm_fp8(mrgan_handle* h, int epi, const GemmArgs& g, double algo_flops, hipStream_t s) {
+    const char* kname = "gemm_fp8";
+    prof_arm(h);
+    const int r = launch_gemm_fp8(epi, g, s, &kname);
+    // operands are bytes; outputs: fp8 (+ transposed copy) or bf16, the weight gradient fp32
+    const Epi& e = g.e;
+    const double out_b = epi == EPI_SLAB ? 4.0 : (e.out ? 2.0 : 0.0) + (e.q8 ? 1.0 : 0.0) + (e.q8t ? 1.0 : 0.0);
+    const double bytes = (double)g.nbatch * g.M * g.K + (double)g.K * g.N + (double)g.nbatch * g.M * g.N * out_b;
+    prof_done(h, kname, algo_flops, bytes);
+    if (r) return fail(r, "fp8 product launch failed (%d)", r);
+    return 0;
+}
+int fp8_quant(mrgan_handle* h, const void* src, long src_bs, int ld, int rows, int cols, int prow, int nb, unsigned char* dst, long dst_bs,
+              int ldd, unsigned char* dstt, long dstt_bs, int lddt, int slot, int fmt, hipStream_t s) {
+    Quant8Args q;
+    memset(&q, 0, sizeof q);
+    q.src = (const __bf16*)src; q.src_bs = src_bs; q.ld = ld; q.rows = rows; q.cols = cols; q.prow = prow; q.nb = nb;
+    q.dst = dst; q.dst_bs = dst_bs; q.ldd = ldd; q.dstt = dstt; q.dstt_bs = dstt_bs; q.lddt = lddt;
+    q.slot = h->slots + slot; q.fmt = fmt;
+    PROFB("quant8_kernel", launch_quant8(q, s), (double)nb * prow * cols * (2.0 + (dst ? 1.0 : 0.0) + (dstt ? 1.0 : 0.0)));
+    return 0;
+}
+// the noisy input rows of dense 1 (xin[0] slots x0_slot .. + nb) -> x8[0] (+ transposed)
+int fp8_quant_x0(mrgan_handle* h, int x0_slot, int nb, bool want_t, hipStream_t s) {
+    const int S = h->S, Dp = h->Dp;
+    return fp8_quant(h, rowptr(h, h->xin[0], (long)x0_slot * S, Dp), (long)S * Dp, Dp, h->B, Dp, (int)round_up(h->B, 64), nb, h->x8[0],
+                     (long)S * Dp, Dp, want_t ? h->x8t[0] : nullptr, S, 3 * S, slot_x(h->fp8_kind, 0), FP8_E4M3, s);
+}
+int fp8_quant_top_grad(mrgan_handle* h, int nb, bool want_t, hipStream_t s) {
+    const int S = h->S, Fp = h->Fp;
+    return fp8_quant(h, h->dpre[4], (long)S * Fp, Fp, h->B, Fp, (int)round_up(h->B, 64), nb, h->g8[4], (long)S * Fp, Fp,
+                     want_t ? h->g8t[4] : nullptr, S, 3 * S, slot_g(h->fp8_kind, 4), FP8_E5M2, s);
+}
+int fp8_refresh_weights(mrgan_handle* h, hipStream_t s) {
+    for (int l = 0; l < 5; ++l) {
+        const Dense& L = h->d[l];
+        CHK(fp8_quant(h, L.W->w16, 0, L.Np, L.Kp, L.Np, L.Kp, 1, h->w8[l], 0, L.Np, h->w8t[l], 0, L.Kp, slot_w(l), FP8_E4M3, s));
+    }
+    return 0;
+}
+int fp8_update_scales(mrgan_handle* h, hipStream_t s) {
+    PROF("fp8_update_scales_kernel", launch_fp8_update_scales(h->slots, FP8_NSLOT, s));
+    return 0;
+}
+GemmArgs fp8_args(mrgan_handle* h, int M, int N, int K, int nb) {
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.M = M; g.N = N; g.K = K; g.nbatch = nb; g.splits = 1; g.kchunk = K; g.tiles_m = ceil_div(M, 64);
+    g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
+    g.a_sk = 1; g.b_sk = 1;
+    g.e = base_epi(h);
+    return g;
+}
+// dense l + relu (+ the next layer's GaussianNoise): x8[l] -> x8[l + 1] (+ transposed), the feature layer -> feat (bf16)
+int fp8_fwd(mrgan_handle* h, int l, int nb, bool want_t, bool fm_sums, hipStream_t s) {
+    const Dense& L = h->d[l];
+    const int S = h->S, kind = h->fp8_kind;
+    const bool last = l == 4;
+    GemmArgs g = fp8_args(h, h->B, L.Np, L.Kp, nb);
+    g.A = h->x8[l]; g.a_bs = (long)S * L.Kp; g.a_si = L.Kp;
+    g.B = h->w8t[l]; g.b_sj = L.Kp;
+    Epi& e = g.e;
+    e.act = ACT_RELU; e.n_valid = L.N; e.bias = L.b->p;
+    e.out = last ? h->feat : nullptr; e.out_bs = (long)S * L.Np; e.ldo = L.Np;
+    e.sigma = last ? 0.f : h->cfg.sigma[l + 1]; e.site = (uint32_t)(l + 1); e.seg0 = 0;
+    e.mask = h->mask[l]; e.mask_bs = (long)(S / 32) * h->ldm[l] * 2; e.ldm = h->ldm[l];
+    e.cs_mode = (last && fm_sums) ? CS_SUM : CS_NONE; e.cs1 = h->cs_f; e.ldcs = L.Np;
+    e.qa = h->slots + slot_x(kind, l); e.qb = h->slots + slot_w(l);
+    if (!last) {
+        e.qo = h->slots + slot_x(kind, l + 1); e.q_fmt = FP8_E4M3;
+        e.q8 = h->x8[l + 1]; e.q8_bs = (long)S * L.Np; e.ldq8 = L.Np;
+        if (want_t) { e.q8t = h->x8t[l + 1]; e.q8t_bs = S; e.ldq8t = 3 * S; }
+    }
+    return run_gemm_fp8(h, EPI_FWD, g, 2.0 * h->B * nb * L.K * L.N, s);
+}
+// dX through dense l: g8[l] -> g8[l - 1] (+ transposed) with the relu mask of layer l - 1 and its bias-gradient column sums;
+// l == 0: d loss / d(generator output) -> dxfake (bf16)
+int fp8_dx(mrgan_handle* h, int l, int nb, bool want_t, bool bias_sums, hipStream_t s) {
+    const Dense& L = h->d[l];
+    const int S = h->S, kind = h->fp8_kind;
+    GemmArgs g = fp8_args(h, h->B, L.Kp, L.Np, nb);
+    g.A = h->g8[l]; g.a_bs = (long)S * L.Np; g.a_si = L.Np;
+    g.B = h->w8[l]; g.b_sj = L.Np;
+    Epi& e = g.e;
+    e.qa = h->slots + slot_g(kind, l); e.qb = h->slots + slot_w(l);
+    e.ldcs = L.Kp;
+    if (l > 0) {
+        e.act = ACT_RELU; e.n_valid = h->d[l - 1].N;
+        e.mask = h->mask[l - 1]; e.mask_bs = (long)(S / 32) * h->ldm[l - 1] * 2; e.ldm = h->ldm[l - 1];
+        e.cs_mode = bias_sums ? CS_SUM : CS_NONE; e.cs1 = h->cs_db[l - 1];
+        e.qo = h->slots + slot_g(kind, l - 1); e.q_fmt = FP8_E5M2;
+        e.q8 = h->g8[l - 1]; e.q8_bs = (long)S * L.Kp; e.ldq8 = L.Kp;
+        if (want_t) { e.q8t = h->g8t[l - 1]; e.q8t_bs = S; e.ldq8t = 3 * S; }
+    } else {
+        e.act = ACT_LINEAR; e.n_valid = h->cfg.d_in;
+        e.out = h->dxfake; e.out_bs = (long)S * L.Kp; e.ldo = L.Kp;
+        e.cs_mode = CS_SUM; e.cs1 = h->cs_db3g;
+    }
+    return run_gemm_fp8(h, EPI_DX, g, 2.0 * h->B * nb * L.K * L.N, s);
+}
+// dW_l = x8t[l] g8t[l]^T over the 3 S rows of the D sub-step (rows >= batch of a segment are zero in both), one fp32 slab
+int fp8_dw(mrgan_handle* h, int l, int nseg, hipStream_t s) {
+    const Dense& L = h->d[l];
+    const int S = h->S, kind = h->fp8_kind;
+    GemmArgs g = fp8_args(h, L.Kp, L.Np, nseg * S, 1);
+    g.tiles_m = ceil_div(L.Kp, 128);
+    g.A = h->x8t[l]; g.a_si = 3 * S;
+    g.B = h->g8t[l]; g.b_sj = 3 * S;
+    g.e.qa = h->slots + slot_x(kind, l); g.e.qb = h->slots + slot_g(kind, l);
+    g.e.ldo = L.Np; g.e.slab = L.slabs; g.e.slab_stride = (long)L.Kp * L.Np;
+    return run_gemm_fp8(h, EPI_SLAB, g, 2.0 * h->B * nseg * L.K * L.N, s);
+}
+int fp8_disc_fwd(mrgan_handle* h, int nb, bool want_t, bool fm_sums, int x0_slot, hipStream_t s) {
+    CHK(fp8_quant_x0(h, x0_slot, nb, want_t, s));
+    for (int l = 0; l < 5; ++l) CHK(fp8_fwd(h, l, nb, want_t, fm_sums, s));
+    return 0;
+}
 // per-block partial rows the loss head wrote in this sub-step
 int head_blocks(const mrgan_handle* h) { return 3 * ceil_div(h->B, h->use_chain ? CH_ROWS : HEAD_ROWS); }
 
@@ -602,6 +749,7 @@ int gen_fwd_tail(mrgan_handle* h, int nb, int fake_seg_slot, uint32_t fake_seg_i
 
 // discriminator dense 1..5 over nb segments (learning phase 1: noise on)
 int disc_fwd_train(mrgan_handle* h, int nb, bool fm_sums, int x0_slot, hipStream_t s, int l_end = 5) {
+    if (h->fp8) return fp8_disc_fwd(h, nb, /*want_t=*/h->fp8_kind == 0, fm_sums, x0_slot, s);
     for (int l = 0; l < l_end; ++l) {
         const void* in = l == 0 ? rowptr(h, h->xin[0], (long)x0_slot * h->S, h->Dp) : h->xin[l];
         void* out = l < 4 ? h->xin[l + 1] : h->feat;
@@ -709,6 +857,7 @@ void data_seg(StageSeg& sg, mrgan_handle* h, const float* x, const int32_t* idx,
 // ---------------------------------------------------------------------------------------------------
 int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t s) {
     const int B = h->B;
+    h->fp8_kind = 0;
     if (phase == MRGAN_D_GEN) {
         prof_backlog(h, s);
         StageArgs st;
@@ -766,6 +915,12 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         } else {
             PROF("head_kernel", launch_head(h->bf16, hd, s));
         }
+        if (h->fp8) {
+            CHK(fp8_quant_top_grad(h, 3, true, s));
+            for (int l = 4; l >= 1; --l) CHK(fp8_dx(h, l, 3, true, true, s));
+            for (int l = 0; l < 5; ++l) CHK(fp8_dw(h, l, 3, s));
+            PROF("reduce_partials_kernel", launch_reduce_partials(h->head_part, head_blocks(h), h->head_stride, h->head_stride, h->head_groups, h->head_red, s));
+        } else {
         for (int l = h->use_chain ? 1 : 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 3, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_SUM, h->cs_db[l - 1], nullptr, s));
@@ -776,9 +931,11 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
             const FoldJob fold = {h->head_part, h->head_red, (long)h->head_stride, head_blocks(h), h->head_stride, h->head_groups, 0};
             CHK(dense_dw_all(h, jobs, 5, B, 3, s, &fold));
         }
+        }
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_D, ADAM_REDUCE_ONLY, true, s));
     } else if (phase == MRGAN_D_ADAM) {
         CHK(run_adam(h, MRGAN_NET_D, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, true, s));
+        if (h->fp8) { CHK(fp8_refresh_weights(h, s)); CHK(fp8_update_scales(h, s)); }
         h->cur ^= 1;
     }
     return 0;
@@ -789,6 +946,7 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
 // ---------------------------------------------------------------------------------------------------
 int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s) {
     const int B = h->B, tm = h->tiles_m, N1p = h->g[0].Np;
+    h->fp8_kind = 1;
     if (phase == MRGAN_G_GEN) {
         prof_backlog(h, s);
         StageArgs st;
@@ -850,12 +1008,17 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         } else {
             PROF("fm_kernel", launch_fm(h->bf16, f, s));
         }
+        if (h->fp8) {
+            CHK(fp8_quant_top_grad(h, 1, false, s));
+            for (int l = 4; l >= 0; --l) CHK(fp8_dx(h, l, 1, false, false, s));
+        } else {
         for (int l = h->use_chain ? 1 : 4; l >= 1; --l)
             CHK(dense_dx(h, h->d[l], h->dpre[l], B, 1, h->dpre[l - 1], ACT_RELU, h->d[l - 1].N, h->mask[l - 1], h->ldm[l - 1],
                          nullptr, CS_NONE, nullptr, nullptr, s));
         // d loss / d(generator output): noise is additive, so this is also d/d(fake x)
         CHK(dense_dx(h, h->d[0], h->dpre[0], B, 1, h->dxfake, ACT_LINEAR, h->cfg.d_in, nullptr, 0, nullptr, CS_SUM, h->cs_db3g,
                      nullptr, s));
+        }
         CHK(dense_dx(h, h->g[2], h->dxfake, B, 1, h->dpre2g, ACT_SOFTPLUS, h->g[1].N, nullptr, 0, h->h2, CS_SUM, h->cs_db2g,
                      nullptr, s));
         CHK(dense_dx(h, h->g[1], h->dpre2g, B, 1, h->dhbn, ACT_LINEAR, h->g[0].N, nullptr, 0, h->h1, CS_SUM_XHAT, h->cs_dbeta,
@@ -879,6 +1042,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_G, ADAM_REDUCE_ONLY, false, s));
     } else if (phase == MRGAN_G_ADAM) {
         CHK(run_adam(h, MRGAN_NET_G, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, false, s, a->stream_mode ? 1 : 0));
+        if (h->fp8) CHK(fp8_update_scales(h, s));
         h->cur ^= 1;
     }
     return 0;
@@ -1047,6 +1211,7 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
     h->cur = 0; h->graph_ready = false; h->graph_exec = nullptr; h->prof = false;
     h->pair_gen = h->gen_ready = 0; h->pair_g = nullptr; h->real_staged = 0;
     h->tune_kc_cfg = -1; h->tune_bits = 0; h->tune_pair_gen = 1; h->ablate = 0;
+    h->fp8_kind = 0; h->fp8_cal[0] = h->fp8_cal[1] = 0;
     if (init_kernel_attributes() != 0 || chain_init_attributes() != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "hipFuncSetAttribute failed"); }
 #define CREATE_CHK(x)                                           \
     do {                                                        \
@@ -1063,6 +1228,15 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
     r = upload_tiles(h, h->gt, h->tiles_g_dev, h->ntiles_g, s);
     if (!r) r = upload_tiles(h, h->dt, h->tiles_d_dev, h->ntiles_d, s);
     if (r) { if (h->own_ws) hipFree(h->ws); delete h; return r; }
+    if (h->fp8) {
+        float tg[FP8_NSLOT];
+        for (int k = 0; k < 2; ++k)
+            for (int l = 0; l < 5; ++l) { tg[slot_x(k, l)] = FP8_TARGET_E4M3; tg[slot_g(k, l)] = FP8_TARGET_E5M2; }
+        for (int l = 0; l < 5; ++l) tg[slot_w(l)] = FP8_TARGET_E4M3;
+        CREATE_CHK(hipMemcpyAsync(h->slot_targets, tg, sizeof tg, hipMemcpyHostToDevice, s));
+        CREATE_CHK(hipStreamSynchronize(s));
+        if (launch_fp8_init_slots(h->slots, FP8_NSLOT, h->slot_targets, s) != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "fp8 slot init failed"); }
+    }
     // BN gamma defaults to one (Keras); dense weights stay zero until mrgan_set_weights
     std::vector<float> ones(h->gt[2].cols, 1.0f);
     CREATE_CHK(hipMemcpyAsync(h->gt[2].p, ones.data(), sizeof(float) * ones.size(), hipMemcpyHostToDevice, s));
@@ -1099,6 +1273,10 @@ int mrgan_set_weights(mrgan_handle* h, int net, int idx, const float* src, mrgan
     HIPCHK(hipMemcpy2DAsync(t->p, sizeof(float) * t->pcol, src, sizeof(float) * t->cols, sizeof(float) * t->cols, t->rows,
                             hipMemcpyDeviceToDevice, s));
     if (t->w16) hipLaunchKernelGGL(refresh_bf16_kernel, grid2d(t->prow, t->pcol), dim3(256), 0, s, t->p, t->w16, t->wt16, t->prow, t->pcol);
+    if (h->fp8 && net == MRGAN_NET_D && t->w16) {
+        // fp8 copies of the discriminator's weights: the first pass only measures max |w|, the second stores with that scale
+        for (int pass = 0; pass < 2; ++pass) { CHK(fp8_refresh_weights(h, s)); CHK(fp8_update_scales(h, s)); }
+    }
     return 0;
 }
 
@@ -1150,6 +1328,15 @@ int mrgan_disc_step(mrgan_handle* h, const mrgan_disc_args* a, int p0, int p1, f
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     if (p1 < 0) p1 = MRGAN_D_NPHASES - 1;
+    if (h->fp8 && p0 == 0 && !h->fp8_cal[0]) {
+        // first D sub-step of an fp8 handle: dry passes (forward + backward, no update) settle the delayed scales, one
+        // layer of the gradient chain per pass
+        for (int i = 0; i < FP8_DRY_PASSES; ++i) {
+            for (int p = MRGAN_D_GEN; p <= MRGAN_D_MAIN; ++p) { r = disc_phase(h, a, p, s); if (r) return r; }
+            CHK(fp8_update_scales(h, s));
+        }
+        h->fp8_cal[0] = 1;
+    }
     for (int p = p0; p <= p1; ++p) { r = disc_phase(h, a, p, s); if (r) return r; }
     if (out3) {
         HIPCHK(hipMemcpyAsync(out3, h->step_out, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1164,6 +1351,17 @@ int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int p0, int p1, flo
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     if (p1 < 0) p1 = MRGAN_G_NPHASES - 1;
+    if (h->fp8 && p0 == 0 && !h->fp8_cal[1]) {
+        // same for the G sub-step's tensors (its own slots: the feature-matching gradient has another scale than the D loss's);
+        // the feature-matching kernel adds its loss to the epoch accumulator, which the dry passes must leave alone
+        HIPCHK(hipMemcpyAsync(h->accum_save, h->accum, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        for (int i = 0; i < FP8_DRY_PASSES; ++i) {
+            for (int p = MRGAN_G_GEN; p <= MRGAN_G_BWD; ++p) { r = gen_phase(h, a, p, s); if (r) return r; }
+            CHK(fp8_update_scales(h, s));
+        }
+        HIPCHK(hipMemcpyAsync(h->accum, h->accum_save, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        h->fp8_cal[1] = 1;
+    }
     for (int p = p0; p <= p1; ++p) { r = gen_phase(h, a, p, s); if (r) return r; }
     if (out1) {
         HIPCHK(hipMemcpyAsync(out1, h->step_out + 3, sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1186,6 +1384,7 @@ int mrgan_sup_step(mrgan_handle* h, const mrgan_sup_args* a, float* out2, mrgan_
     if (!h || !a || !a->x_dev || !a->labels_dev) return fail(-1, "sup_step: x and labels are required");
     if (a->ld_x < h->cfg.d_in) return fail(-2, "sup_step: row pitch smaller than d_in");
     if (h->flat_grads || h->cfg.world != 1) return fail(-3, "sup_step: single-GPU handles only");
+    if (h->fp8) return fail(-3, "sup_step: the fp8 mode covers the GAN step only");
     if (a->rows_valid < 0 || a->rows_valid > h->B) return fail(-2, "sup_step: rows_valid outside [0, batch]");
     if (a->rows_valid && a->stream_mode) return fail(-2, "sup_step: a short batch cannot be combined with stream mode");
     hipStream_t s = (hipStream_t)stream;
@@ -1221,7 +1420,7 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
         h->gen_ready = 0;
         return rr;
     };
-    if (!want_graph) return both();
+    if (!want_graph || (h->fp8 && !(h->fp8_cal[0] && h->fp8_cal[1]))) return both();     // (the calibrating first pair runs eagerly)
     // A pair flips the state slot twice, so every kernel argument is identical on every replay as long as
     // the slot parity and the caller's pointers are those of the capture.
     if (h->graph_ready && (h->graph_cur != h->cur || memcmp(&h->graph_d, d, sizeof *d) != 0 || memcmp(&h->graph_g, g, sizeof *g) != 0)) {
@@ -1460,7 +1659,7 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
 // fp8 forward product (gemm_fp8.hip): out[m,n] = act((q(a * scale_a) q(b * scale_b)) / (scale_a scale_b) + bias), q = e4m3 RNE.
 // reps > 0: returns the average device time of `reps` launches in *avg_us instead of writing `out` through fp32.
 int mrgan_debug_gemm_fp8(int m, int n, int k, const float* a, const float* b, const float* bias, int act, float scale_a, float scale_b,
-                         float* out, int reps, float* avg_us, mrgan_stream stream) {
+                         float* out, int reps, float* avg_us, int kc_cfg, mrgan_stream stream) {
     if ((n % 64) || (k % 128) || !a || !b) return fail(-1, "debug_gemm_fp8: n %% 64 == 0 and k %% 128 == 0 are required");
     hipStream_t s = (hipStream_t)stream;
     unsigned char *ta = nullptr, *tb = nullptr;
@@ -1476,14 +1675,14 @@ int mrgan_debug_gemm_fp8(int m, int n, int k, const float* a, const float* b, co
     g.seg_stride = 1 << 30; g.seg_rows = 1 << 30;
     g.A = ta; g.a_si = k; g.a_sk = 1; g.B = tb; g.b_sj = k; g.b_sk = 1;
     g.e.act = act; g.e.n_valid = n; g.e.bias = bias; g.e.out = to; g.e.ldo = n; g.e.acc_scale = 1.0f / (scale_a * scale_b);
-    g.e.tune_kc_cfg = -1;
-    int r = launch_gemm_fp8_fwd(g, s);
+    g.e.tune_kc_cfg = kc_cfg;
+    int r = launch_gemm_fp8(EPI_FWD, g, s);
     if (!r && reps > 0 && avg_us) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipEventRecord(e0, s));
-        for (int i = 0; i < reps && !r; ++i) r = launch_gemm_fp8_fwd(g, s);
+        for (int i = 0; i < reps && !r; ++i) r = launch_gemm_fp8(EPI_FWD, g, s);
         HIPCHK(hipEventRecord(e1, s));
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0.f;

@@ -23,6 +23,11 @@ enum { EPI_FWD = 0, EPI_DX = 1, EPI_SLAB = 2 };
 // (the fp32 parity kernels, where epilogue speed is irrelevant).
 enum { VAR_ACT_MASK = 3, VAR_NOISE = 4, VAR_MASK = 8, VAR_DYN = 64 };
 
+// one fp8 tensor's scaling state.  Delayed scaling: a pass stores with `scale` (from the amax of the previous pass) and
+// records its own max |v| (before scaling); fp8_update_scales_kernel turns that into the next pass's scale.
+struct Fp8Slot { uint32_t amax_bits; float scale, inv_scale; float target; };
+enum { FP8_E4M3 = 0, FP8_E5M2 = 1 };
+
 struct Epi {
     int act;                 // FWD: activation; DX: derivative applied (RELU mask / SOFTPLUS from h / LINEAR)
     int n_valid;             // logical number of output columns; columns beyond are forced to zero
@@ -39,7 +44,13 @@ struct Epi {
     float* slab; long slab_stride;              // SLAB: fp32 [split][rows][ldo]
     const DevState* st;
     int ablate;              // timing experiments only: 2 = skip the epilogue, 4 = skip the main loop (one branch each)
-    float acc_scale;         // fp8 forward: 1 / (scale of A * scale of B), applied to the accumulator before the bias
+    float acc_scale;         // fp8 products: 1 / (scale of A * scale of B), applied to the accumulator (when qa is null)
+    // fp8 path (gemm_fp8.hip).  Every fp8 tensor has a slot {amax of the last pass, power-of-two scale, 1 / scale}.
+    const Fp8Slot* qa; const Fp8Slot* qb;     // operand slots: accumulator *= qa->inv_scale * qb->inv_scale
+    Fp8Slot* qo;                              // output slot: stored byte = fp8(v * qo->scale); max |v| -> qo->amax_bits
+    void* q8; long q8_bs; int ldq8;           // fp8 copy of the output tile [batch][rows][ldq8]   (null: none)
+    void* q8t; long q8t_bs; int ldq8t;        // transposed fp8 copy [cols][ldq8t], batch b at element offset b * q8t_bs
+    int q_fmt;                                // 0 = e4m3, 1 = e5m2
     int tune_kc_cfg;         // forward / dX tile config forced by mrgan_set_tuning (-1 = measured table)
     int tune_bits;           // TUNE_BIT_* of the handle
 };
@@ -254,7 +265,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             __syncthreads();
             for (int cidx = threadIdx.x; cidx < bm * chunks_per_row; cidx += blockDim.x) {
                 const int r = cidx / chunks_per_row, c = cidx - r * chunks_per_row;
-                if (row_blk + r < M && col_blk + c * EPV < g.N)
+                if (e.out && row_blk + r < M && col_blk + c * EPV < g.N)          // (fp8 path: out may be null, only q8 / q8t are kept)
                     *(u32x4_t*)(out + (long)(row_blk + r) * e.ldo + col_blk + c * EPV) = *(const u32x4_t*)(tile + r * bn + c * EPV);
             }
         }
@@ -360,9 +371,21 @@ struct KsGroup {
 // kname (optional) receives the name of the kernel instantiation that was launched, spelled as rocprofv3 prints it
 int launch_gemm_f32(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
 int launch_gemm_bf16(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
-int launch_gemm_fp8_fwd(const GemmArgs& g, hipStream_t s, const char** kname = nullptr);      // gemm_fp8.hip
+// gemm_fp8.hip: fp8 operands (g.A [M][K] bytes, g.B = Bt [N][K] bytes, K % 128 == 0); formats fixed per product
+int launch_gemm_fp8(int epi, const GemmArgs& g, hipStream_t s, const char** kname = nullptr);
 int launch_to_fp8(const float* src, long ld_src, unsigned char* dst, long ld_dst, int rows, int cols, int prow, int pcol, float scale,
                   int transpose, hipStream_t s);
+// bf16 [nb][rows][ld] -> fp8 copy and / or transposed fp8 copy, scaled by slot->scale; records max |v| in the slot
+struct Quant8Args {
+    const __bf16* src; long src_bs; int ld; int rows, cols, nb;      // cols: padded width (multiple of 64); rows >= `rows` store zeros
+    int prow;                                                         // rows written per batch (multiple of 64, >= rows)
+    unsigned char* dst; long dst_bs; int ldd;
+    unsigned char* dstt; long dstt_bs; int lddt;
+    Fp8Slot* slot; int fmt;
+};
+int launch_quant8(const Quant8Args& a, hipStream_t s);
+int launch_fp8_update_scales(Fp8Slot* slots, int n, hipStream_t s);
+int launch_fp8_init_slots(Fp8Slot* slots, int n, const float* targets_dev, hipStream_t s);
 int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const char** kname = nullptr,
                               const FoldJob* fold = nullptr);   // 1 = not applicable
 

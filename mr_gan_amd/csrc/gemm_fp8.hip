@@ -1,14 +1,22 @@
-// fp8 (OCP e4m3) forward product on the matrix cores: Y[M][N] = act((A[M][K] Bt[N][K]^T) / (sA sB) + b), bf16 out.
+// fp8 products on the matrix cores (OCP e4m3 / e5m2 operands, fp32 accumulate): the three products of a dense layer for
+// the wide stack BASELINE configs[4] asks for (hidden 4096 x 5, batch 8192).
 //
-// First member of the fp8 family BASELINE configs[4] asks for (hidden 4096 x 5): v_mfma_f32_32x32x16_fp8_fp8, fp32
-// accumulate, per-tensor power-of-two scales sA / sB applied to the accumulator.  The non-scaled fp8 MFMA issues at the bf16
-// rate (MI355X_MICROARCH.md, Matrix cores); what fp8 buys here is bytes: an operand tile of [rows][128 B] now holds 128
-// reduction elements instead of 64, so the L2 -> LDS fill -- which bounds the bf16 forward kernels of this build at 128x128
-// tiles -- is halved per FLOP.  Structure = the bf16 KC kernel (gemm_bf16.hip): LDS-DMA
-// (buffer_load ... lds) into an XOR-swizzled 2-stage ring, one s_barrier per k-tile, persistent blocks in XCD-aware
-// tile order, the shared fused epilogue of gemm.h.  Fragments are 8-byte ds_read_b64 (8 fp8 per lane and k-step).
-// Used through mrgan_debug_gemm_fp8 / mrgan_debug_gemm_time (kernel-level parity and timing); the training path does not
-// select it yet (what the engine still needs -- e5m2 gradients, scale tracking in the Adam kernel).
+//   FWD   Y  = act(X W + b) (+ noise)     A = X    e4m3 [rows][K]     Bt = W^T  e4m3 [N][K]
+//   DX    dX = (dY W^T) * relu'           A = dY   e5m2 [rows][N]     Bt = W    e4m3 [K][N]
+//   SLAB  dW = X^T dY                     A = X^T  e4m3 [K][rows]     Bt = dY^T e5m2 [N][rows]    (no split: rows >= 8192)
+// All three are "A Bt^T" with the reduction index contiguous in both operands, so ONE kernel serves them: the producers
+// write every activation / gradient twice, row-major for the next FWD / DX and transposed for the SLAB product.
+//
+// MFMA: v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales -- the only fp8 form that runs at 2x the bf16 rate on
+// gfx950 (MI355X_MICROARCH.md, Matrix cores; the non-scaled 32x32x16_fp8_fp8 form issues at the bf16 rate).  Per-tensor
+// power-of-two scales (Fp8Slot, delayed scaling) are undone on the accumulator.  Lane l holds k = 32 (l >> 5) .. + 31 of row
+// l & 31: two ds_read_b128 per fragment from the same XOR-swizzled [rows][128 B] LDS image as the bf16 kernels, filled by
+// LDS-DMA (buffer_load ... lds) into a 2-stage ring, one s_barrier per k-tile (128 reduction elements), persistent blocks in
+// XCD-aware tile order, 128x128 (4 waves) or 256x256 (8 waves of 128x64) blocks.
+//
+// Epilogue: the shared one of gemm.h (bias / relu / mask / GaussianNoise / column sums) assembles the bf16 tile in LDS;
+// quant_tile then writes it as fp8 (row-major and transposed, 16-byte stores) scaled by the output slot, and records max |v|.
+// The stored byte is therefore fp8(bf16(v)): the oracle's fp8 mirror rounds twice in the same way.
 #include <algorithm>
 #include <string>
 
@@ -18,6 +26,8 @@ namespace mrgan {
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int BKB = 128;                        // reduction BYTES (= fp8 elements) per k-tile
 
 __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -26,12 +36,80 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
-template <int BM, int BNT, int WM, int WN, int VAR>
+// four floats -> four fp8 bytes of v * qs (round to nearest even, saturating at the format's largest finite value)
+template <int FMT>
+__device__ __forceinline__ uint32_t pack4(float a, float b, float c, float d, float qs) {
+    constexpr float LIM = FMT == FP8_E5M2 ? 57344.f : 448.f;
+    a = fminf(fmaxf(a * qs, -LIM), LIM); b = fminf(fmaxf(b * qs, -LIM), LIM);
+    c = fminf(fmaxf(c * qs, -LIM), LIM); d = fminf(fmaxf(d * qs, -LIM), LIM);
+    int w;
+    if constexpr (FMT == FP8_E5M2) { w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true); }
+    else { w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true); }
+    return (uint32_t)w;
+}
+template <int FMT>
+__device__ __forceinline__ u32x4 pack16(const float (&v)[16], float qs) {
+    return (u32x4){pack4<FMT>(v[0], v[1], v[2], v[3], qs), pack4<FMT>(v[4], v[5], v[6], v[7], qs),
+                   pack4<FMT>(v[8], v[9], v[10], v[11], qs), pack4<FMT>(v[12], v[13], v[14], v[15], qs)};
+}
+__device__ __forceinline__ void amax_commit(Fp8Slot* slot, float amax) {
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&slot->amax_bits, __float_as_uint(amax));
+}
+
+// the block's bf16 output tile (LDS, [BM][BNT]) -> fp8 copies in global memory
+template <int BM, int BNT, int NT, int FMT>
+__device__ __forceinline__ void quant_tile(const __bf16* tile, const Epi& e, int batch, int row_blk, int col_blk, int M, int N) {
+    const float qs = e.qo->scale;
+    float amax = 0.f;
+    if (e.q8) {
+        unsigned char* q8 = (unsigned char*)e.q8 + (long)batch * e.q8_bs;
+        constexpr int CPR = BNT / 16;
+        for (int c = threadIdx.x; c < BM * CPR; c += NT) {
+            const int r = c / CPR, cc = (c - r * CPR) * 16;
+            if (row_blk + r < M && col_blk + cc < N) {
+                const bf16x8 lo = *(const bf16x8*)(tile + r * BNT + cc), hi = *(const bf16x8*)(tile + r * BNT + cc + 8);
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i] = (float)lo[i]; v[8 + i] = (float)hi[i]; }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+                *(u32x4*)(q8 + (long)(row_blk + r) * e.ldq8 + col_blk + cc) = pack16<FMT>(v, qs);
+            }
+        }
+    }
+    if (e.q8t) {
+        // 16 rows of one column per thread; neighbouring lanes take neighbouring columns (conflict-free LDS reads).
+        // Rows >= M inside a started 16-row group are stored as zeros, later groups keep the zeros of mrgan_create:
+        // the weight-gradient product reduces over all S rows of a segment.
+        unsigned char* q8t = (unsigned char*)e.q8t + (long)batch * e.q8t_bs;
+        for (int c = threadIdx.x; c < BNT * (BM / 16); c += NT) {
+            const int col = c % BNT, r0 = (c / BNT) * 16;
+            if (row_blk + r0 < M && col_blk + col < N) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = (row_blk + r0 + i < M) ? (float)tile[(r0 + i) * BNT + col] : 0.f;
+                if (!e.q8) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+                }
+                *(u32x4*)(q8t + (long)(col_blk + col) * e.ldq8t + row_blk + r0) = pack16<FMT>(v, qs);
+            }
+        }
+    }
+    amax_commit(e.qo, amax);
+}
+
+// operand formats per product: cbsz (A) / blgp (B) of the scaled MFMA, 0 = e4m3, 1 = e5m2
+template <int EPI> struct Fp8Fmt { static constexpr int A = EPI == EPI_DX ? 1 : 0, B = EPI == EPI_SLAB ? 1 : 0; };
+
+template <int EPI, int BM, int BNT, int WM, int WN, int VAR>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int MR = BM / WM / 32, NR = BNT / WN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BNT / 8 / NW;
+    constexpr int FMT_A = Fp8Fmt<EPI>::A, FMT_B = Fp8Fmt<EPI>::B;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -39,6 +117,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
     const int lrow = lane >> 3, lp = lane & 7, lr = lane & 31, lh = lane >> 5;
     const int ntn = (g.N + BNT - 1) / BNT, ntm = (g.M + BM - 1) / BM;
     const int ntiles = ntn * ntm * g.nbatch, nk = g.K / BKB;
+    // undo the operand scales on the accumulator
+    const float us = g.e.qa ? g.e.qa->inv_scale * g.e.qb->inv_scale : g.e.acc_scale;
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int tidx = xcd_tile(tl, ntiles);
         const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
@@ -77,7 +157,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         EpiPrefetch<MR, NR> pf;
-        epilogue_prefetch<__bf16, EPI_FWD, MR, NR, VAR>(pf, g, batch, row_blk, col_blk, wm, wn, lane);
+        epilogue_prefetch<__bf16, EPI, MR, NR, VAR>(pf, g, batch, row_blk, col_blk, wm, wn, lane);
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of k-tile kt have landed
@@ -87,28 +167,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
             const char* As = lds + buf * STAGE;
             const char* Bs = As + A_BYTES;
             buf ^= 1;
+            // two k-steps of 64 per tile: lane (r = lane & 31, h = lane >> 5) holds elements k = 32 h .. 32 h + 31 of row r
 #pragma unroll
-            for (int kg = 0; kg < 8; kg += 4) {
-                long a[4][MR], b[4][NR];
+            for (int ks = 0; ks < 2; ++ks) {
+                i32x8 a[MR], b[NR];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                    for (int mi = 0; mi < MR; ++mi) a[kk][mi] = *(const long*)(As + kc_off((wm * MR + mi) * 32 + lr, kg + kk) + lh * 8);
-#pragma unroll
-                    for (int ni = 0; ni < NR; ++ni) b[kk][ni] = *(const long*)(Bs + kc_off((wn * NR + ni) * 32 + lr, kg + kk) + lh * 8);
+                for (int mi = 0; mi < MR; ++mi) {
+                    const int row = (wm * MR + mi) * 32 + lr;
+                    const i32x4 lo = *(const i32x4*)(As + kc_off(row, ks * 4 + lh * 2)), hi = *(const i32x4*)(As + kc_off(row, ks * 4 + lh * 2 + 1));
+                    a[mi] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+                for (int ni = 0; ni < NR; ++ni) {
+                    const int row = (wn * NR + ni) * 32 + lr;
+                    const i32x4 lo = *(const i32x4*)(Bs + kc_off(row, ks * 4 + lh * 2)), hi = *(const i32x4*)(Bs + kc_off(row, ks * 4 + lh * 2 + 1));
+                    b[ni] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
 #pragma unroll
-                    for (int mi = 0; mi < MR; ++mi)
+                for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NR; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a[kk][mi], b[kk][ni], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NR; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mi], b[ni], acc[mi][ni], FMT_A, FMT_B, 0, 0, 0, 0);
             }
         }
-        // undo the operand scales on the accumulator, then the shared epilogue (bias / activation / bf16 tile via LDS)
-        const float us = g.e.acc_scale;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -116,13 +197,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= us;
         __syncthreads();
-        epilogue<__bf16, EPI_FWD, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
+        if constexpr (EPI == EPI_SLAB) {
+            epilogue<__bf16, EPI_SLAB, MR, NR, WM, false, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BNT);
+        } else {
+            // shared epilogue (bias / activation / mask / noise / column sums): bf16 tile assembled in LDS, optional bf16 store
+            epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
                                                          (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf, nullptr);
+            if (g.e.q8 || g.e.q8t) {
+                if (g.e.q_fmt == FP8_E5M2) quant_tile<BM, BNT, 64 * NW, FP8_E5M2>((const __bf16*)lds, g.e, batch, row_blk, col_blk, g.M, g.N);
+                else quant_tile<BM, BNT, 64 * NW, FP8_E4M3>((const __bf16*)lds, g.e, batch, row_blk, col_blk, g.M, g.N);
+            }
+        }
         __syncthreads();
     }
 }
 
-// fp32 -> e4m3 (round to nearest even, saturating at +-448) of x * scale: four elements per thread
+// fp32 -> e4m3 (round to nearest even, saturating at +-448) of x * scale (debug entry's operand staging)
 __global__ void to_fp8_kernel(const float* src, long lds_, unsigned char* dst, long ldd, int rows, int cols, int prow, int pcol, float scale, int transpose) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= prow || c >= pcol) return;
@@ -131,6 +221,85 @@ __global__ void to_fp8_kernel(const float* src, long lds_, unsigned char* dst, l
     const int w = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
     if (transpose) dst[(long)c * ldd + r] = (unsigned char)(w & 0xFF);
     else dst[(long)r * ldd + c] = (unsigned char)(w & 0xFF);
+}
+
+// bf16 [nb][rows][ld] -> fp8 (row-major and / or transposed) of v * slot->scale, 64 x 64 tile per block; max |v| -> slot
+template <int FMT>
+__global__ __launch_bounds__(256) void quant8_kernel(const Quant8Args a) {
+    __shared__ __bf16 tl[64][72];
+    const int t = threadIdx.x, batch = blockIdx.z;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    const float qs = a.slot->scale;
+    const __bf16* src = a.src + (long)batch * a.src_bs;
+    const int r = t >> 2, cc = (t & 3) * 16;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    if (row0 + r < a.rows) {
+        const bf16x8 lo = *(const bf16x8*)(src + (long)(row0 + r) * a.ld + col0 + cc), hi = *(const bf16x8*)(src + (long)(row0 + r) * a.ld + col0 + cc + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = (float)lo[i]; v[8 + i] = (float)hi[i]; }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    if (a.dst) *(u32x4*)(a.dst + (long)batch * a.dst_bs + (long)(row0 + r) * a.ldd + col0 + cc) = pack16<FMT>(v, qs);
+    if (a.dstt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tl[r][cc + i] = (__bf16)v[i];
+        __syncthreads();
+        const int col = t & 63, r0 = (t >> 6) * 16;
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = (float)tl[r0 + i][col];
+        *(u32x4*)(a.dstt + (long)(col0 + col) * a.lddt + (long)batch * a.dstt_bs + row0 + r0) = pack16<FMT>(w, qs);
+    }
+    amax_commit(a.slot, amax);
+}
+
+// delayed scaling: next scale = 2^floor(log2(target / amax)) from the exponent field of the fp32 quotient (bit-exact on
+// the CPU mirror); a slot nobody wrote (amax 0) keeps its scale
+__global__ void fp8_update_scales_kernel(Fp8Slot* slots, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    Fp8Slot s = slots[i];
+    const float a = __uint_as_float(s.amax_bits);
+    if (a > 0.f) {
+        const float q = s.target / a;
+        int e = (int)((__float_as_uint(q) >> 23) & 0xFF) - 127;
+        e = max(-100, min(100, e));
+        s.scale = __uint_as_float((uint32_t)(127 + e) << 23);
+        s.inv_scale = __uint_as_float((uint32_t)(127 - e) << 23);
+    }
+    s.amax_bits = 0u;
+    slots[i] = s;
+}
+__global__ void fp8_init_slots_kernel(Fp8Slot* slots, int n, const float* targets) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    slots[i] = Fp8Slot{0u, 1.0f, 1.0f, targets[i]};
+}
+
+template <int EPI, int BM, int BNT, int WM, int WN, int VAR>
+int launch_fp8_cfg(const GemmArgs& g, hipStream_t s) {
+    constexpr int STAGE = BM * 128 + BNT * 128, OUT = BM * BNT * 2 + 4 * WM * BNT * 4;
+    constexpr int LDS = 2 * STAGE > OUT ? 2 * STAGE : OUT;
+    static_assert(LDS <= 160 * 1024, "the ring exceeds the LDS of a CU");
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch;
+    dim3 grid(std::min(tiles, 256 * std::max(1, (160 * 1024) / LDS)));
+    auto kern = gemm_fp8_kc_kernel<EPI, BM, BNT, WM, WN, VAR>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
+        attr = true;
+    }
+    MRGAN_LAUNCH(kern, grid, dim3(64 * WM * WN), LDS, s, g);
+    return 0;
+}
+
+template <int EPI, int VAR>
+int launch_fp8_var(const GemmArgs& g, hipStream_t s, bool big) {
+    return big ? launch_fp8_cfg<EPI, 256, 256, 2, 4, VAR>(g, s) : launch_fp8_cfg<EPI, 128, 128, 2, 2, VAR>(g, s);
 }
 
 }  // namespace
@@ -142,31 +311,64 @@ int launch_to_fp8(const float* src, long ld_src, unsigned char* dst, long ld_dst
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// forward product with e4m3 operands: g.A [M][K] bytes (a_si = row pitch in bytes), g.B = Bt [N][K] bytes (b_sj), K % 128 == 0
-int launch_gemm_fp8_fwd(const GemmArgs& g, hipStream_t s, const char** kname) {
+int launch_quant8(const Quant8Args& a, hipStream_t s) {
+    if ((a.cols % 64) || (a.prow % 64) || (a.ld % 8) || !a.slot || a.nb < 1) return -3;
+    if (a.dst && (a.ldd % 16)) return -3;
+    if (a.dstt && ((a.lddt % 16) || (a.dstt_bs % 16))) return -3;
+    const dim3 grid(a.cols / 64, a.prow / 64, a.nb);
+    if (a.fmt == FP8_E5M2) MRGAN_LAUNCH(quant8_kernel<FP8_E5M2>, grid, dim3(256), 0, s, a);
+    else MRGAN_LAUNCH(quant8_kernel<FP8_E4M3>, grid, dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_fp8_update_scales(Fp8Slot* slots, int n, hipStream_t s) {
+    MRGAN_LAUNCH(fp8_update_scales_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, s, slots, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_fp8_init_slots(Fp8Slot* slots, int n, const float* targets_dev, hipStream_t s) {
+    hipLaunchKernelGGL(fp8_init_slots_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, s, slots, n, targets_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// g.A [M][K] bytes (a_si = row pitch in bytes), g.B = Bt [N][K] bytes (b_sj), K % 128 == 0; formats fixed by the product
+// (FWD e4m3 x e4m3, DX e5m2 x e4m3, SLAB e4m3 x e5m2)
+int launch_gemm_fp8(int epi, const GemmArgs& g, hipStream_t s, const char** kname) {
     if ((g.K % BKB) != 0 || g.a_sk != 1 || g.b_sk != 1 || g.splits != 1) return -3;
     if ((long)g.M * g.a_si >= (1L << 31) || (long)g.N * g.b_sj >= (1L << 31)) return -3;
     const Epi& e = g.e;
-    if (e.sigma > 0.f || e.mask) return -3;                      // (noise / mask variants: with the engine integration)
-    constexpr int BM = 128, BNT = 128, WM = 2, WN = 2;
-    constexpr int STAGE = BM * 128 + BNT * 128, OUT = BM * BNT * 2 + 4 * WM * BNT * 4;
-    constexpr int LDS = 2 * STAGE > OUT ? 2 * STAGE : OUT;
-    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch;
-    dim3 grid(std::min(tiles, 256 * std::max(1, (160 * 1024) / LDS)));
-    static bool attr[3] = {false, false, false};
-#define FP8_LAUNCH(IDX, VARV)                                                                                                   \
-    do {                                                                                                                        \
-        auto kern = gemm_fp8_kc_kernel<BM, BNT, WM, WN, VARV>;                                                                  \
-        if (!attr[IDX]) {                                                                                                       \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2; \
-            attr[IDX] = true;                                                                                                   \
-        }                                                                                                                       \
-        MRGAN_LAUNCH(kern, grid, dim3(64 * WM * WN), LDS, s, g);                                                                \
-    } while (0)
-    if (e.act == ACT_RELU) { FP8_LAUNCH(0, ACT_RELU); if (kname) *kname = "gemm_fp8_kc_kernel<128, 128, 2, 2, 1>"; }
-    else if (e.act == ACT_SOFTPLUS) { FP8_LAUNCH(1, ACT_SOFTPLUS); if (kname) *kname = "gemm_fp8_kc_kernel<128, 128, 2, 2, 2>"; }
-    else { FP8_LAUNCH(2, ACT_LINEAR); if (kname) *kname = "gemm_fp8_kc_kernel<128, 128, 2, 2, 0>"; }
-#undef FP8_LAUNCH
+    if ((e.q8 || e.q8t) && !e.qo) return -3;
+    if (e.q8 && (e.ldq8 % 16)) return -3;
+    if (e.q8t && ((e.ldq8t % 16) || (e.q8t_bs % 16))) return -3;
+    if ((e.qa == nullptr) != (e.qb == nullptr)) return -3;
+    // 256x256 blocks (8 waves of 128x64) once they fill the chip; e.tune_kc_cfg 1 / 3 force the small / large tile
+    const int t256 = ceil_div(g.M, 256) * ceil_div(g.N, 256) * g.nbatch;
+    bool big = g.K >= 1024 && t256 >= 192 && (g.N % 256) == 0;
+    if (e.tune_kc_cfg == 1) big = false;
+    if (e.tune_kc_cfg == 3 && (g.N % 256) == 0) big = true;
+    const bool noise = e.sigma > 0.f, mask = e.mask != nullptr;
+    int r = -3;
+    const char* nm = "?";
+    if (epi == EPI_FWD) {
+        nm = big ? "gemm_fp8_kc_kernel<0, 256, 256>" : "gemm_fp8_kc_kernel<0, 128, 128>";
+        if (e.cs_mode != CS_NONE && e.cs_mode != CS_SUM) return -3;
+        if (e.act == ACT_RELU && noise && mask) r = launch_fp8_var<EPI_FWD, ACT_RELU | VAR_NOISE | VAR_MASK>(g, s, big);
+        else if (e.act == ACT_RELU && !noise && mask) r = launch_fp8_var<EPI_FWD, ACT_RELU | VAR_MASK>(g, s, big);
+        else if (e.act == ACT_RELU && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_RELU>(g, s, big);
+        else if (e.act == ACT_LINEAR && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_LINEAR>(g, s, big);
+        else if (e.act == ACT_SOFTPLUS && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_SOFTPLUS>(g, s, big);
+    } else if (epi == EPI_DX) {
+        nm = big ? "gemm_fp8_kc_kernel<1, 256, 256>" : "gemm_fp8_kc_kernel<1, 128, 128>";
+        if (e.cs_mode != CS_NONE && e.cs_mode != CS_SUM) return -3;
+        if (e.act == ACT_RELU && mask) r = launch_fp8_var<EPI_DX, ACT_RELU>(g, s, big);
+        else if (e.act == ACT_LINEAR) r = launch_fp8_var<EPI_DX, ACT_LINEAR>(g, s, big);
+    } else if (epi == EPI_SLAB) {
+        nm = big ? "gemm_fp8_kc_kernel<2, 256, 256>" : "gemm_fp8_kc_kernel<2, 128, 128>";
+        if (!e.slab) return -3;
+        r = launch_fp8_var<EPI_SLAB, ACT_LINEAR>(g, s, big);
+    }
+    if (kname) *kname = nm;
+    if (r) return r;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmrgan_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 NET_G, NET_D = 0, 1
 FLAG_SYNC_STATS, FLAG_FLAT_GRADS, FLAG_GRAPH = 1, 2, 4
 D_GEN, D_MAIN, D_ADAM = 0, 1, 2
@@ -363,12 +363,12 @@ def debug_gemm_time(op, m, n, k, nbatch=1, splits=1, reps=50, ablate=0, kc_cfg=-
     return us.value
 
 
-def debug_gemm_fp8(a, b, bias=None, act=0, scale_a=1.0, scale_b=1.0, reps=0):
+def debug_gemm_fp8(a, b, bias=None, act=0, scale_a=1.0, scale_b=1.0, reps=0, kc_cfg=-1):
     """e4m3 forward product act((q(a sa) q(b sb)) / (sa sb) + bias) -> (fp32 [m, n] result, average us per launch if reps > 0)"""
     m, k = a.shape
     n = b.shape[1]
     out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     us = C.c_float()
     _check(load_library().mrgan_debug_gemm_fp8(m, n, k, _ptr(a), _ptr(b), _ptr(bias), act, C.c_float(scale_a), C.c_float(scale_b), _ptr(out),
-                                               reps, C.byref(us), _stream()))
+                                               reps, C.byref(us), int(kc_cfg), _stream()))
     return out, us.value

@@ -33,7 +33,7 @@ class MRGAN(object):
         self.batch_size = int(batch_size)
         self.seed = int(np.random.randint(1 << 31)) if seed is None else int(seed)   # mr_gan.py:75 is unseeded
         cfg = E.default_config(self.input_dim, self.batch_size)
-        cfg.dtype = {'float32': E.F32, 'fp32': E.F32, 'bfloat16': E.BF16, 'bf16': E.BF16}[dtype]
+        cfg.dtype = {'float32': E.F32, 'fp32': E.F32, 'bfloat16': E.BF16, 'bf16': E.BF16, 'fp8': E.FP8, 'float8': E.FP8}[dtype]
         cfg.num_classes, cfg.noise_size = num_classes, noise_size
         cfg.g_hidden[0], cfg.g_hidden[1] = g_hidden
         for i, w in enumerate(d_hidden):

@@ -341,6 +341,9 @@ class MRGANOracle(object):
 # the HIP engine (mr_gan_amd/csrc/engine.hip), so that a reduced-precision engine can be held to a tight tolerance.
 #   quantize=None   : no rounding anywhere -> must agree with MRGANOracle to fp64 round-off (tests/test_oracle.py),
 #                     which pins the mirror's structure to the autograd-checked restatement.
+#   quantize='fp8'  : the bf16 dataflow, with the operands of the discriminator's dense products (forward, dX, dW)
+#                     additionally rounded to OCP fp8 (e4m3 activations / weights, e5m2 gradients) under delayed per-tensor
+#                     power-of-two scales, as gemm_fp8.hip stores them: fp8(bf16(v) * scale).
 #   quantize='bf16' : every tensor the engine STORES as bf16 is rounded (RNE) where the engine rounds it: GEMM weight
 #                     copies, z, the noisy layer inputs, h1 / BN(h1) / h2, every dpre / dX activation.  Batch
 #                     statistics, bias gradients and column sums come from the unrounded fp32 values, as on the device;
@@ -359,6 +362,43 @@ def _ident(x):
     return x
 
 
+FP8_FORMATS = {'e4m3': (3, -6, 448.0), 'e5m2': (2, -14, 57344.0)}      # OCP: mantissa bits, smallest normal exponent, largest finite
+FP8_TARGETS = {'e4m3': 224.0, 'e5m2': 28672.0}                          # engine.hip FP8_TARGET_*: half the largest finite value
+FP8_DRY_PASSES = 5                                                      # engine.hip FP8_DRY_PASSES
+
+
+def fp8_round(x, fmt):
+    """round to nearest even onto the OCP fp8 grid `fmt` (subnormals included), saturating -- what v_cvt_pk_fp8_f32 /
+    v_cvt_pk_bf8_f32 do to the clamped input (gemm_fp8.hip pack4)"""
+    mant, emin, lim = FP8_FORMATS[fmt]
+    x = np.clip(np.asarray(x, dtype=np.float64), -lim, lim)
+    _, e = np.frexp(np.abs(x))                        # |x| = m 2^e, m in [0.5, 1)
+    quantum = np.exp2(np.maximum(e - 1, emin) - mant)
+    return np.rint(x / quantum) * quantum
+
+
+class Fp8Slots(object):
+    """delayed per-tensor power-of-two scales (gemm.h Fp8Slot, fp8_update_scales_kernel)"""
+
+    def __init__(self):
+        self.scale, self.amax, self.fmt = {}, {}, {}
+
+    def quant(self, v, key, fmt):
+        """v: bf16-valued array -> dequantised fp8(v * scale) / scale; records max |v| for the next pass's scale"""
+        self.fmt[key] = fmt
+        sc = self.scale.get(key, np.float32(1.0))
+        self.amax[key] = max(self.amax.get(key, np.float32(0.0)), np.float32(np.abs(v).max() if v.size else 0.0))
+        return fp8_round(np.asarray(v, np.float32).astype(np.float64) * float(sc), fmt) / float(sc)
+
+    def update(self):
+        for key, a in self.amax.items():
+            if a > 0:
+                ratio = np.float32(FP8_TARGETS[self.fmt[key]]) / np.float32(a)
+                _, e = np.frexp(ratio)
+                self.scale[key] = np.float32(2.0) ** int(np.clip(e - 1, -100, 100))
+            self.amax[key] = np.float32(0.0)
+
+
 class MRGANMirror(object):
     """train_batch_disc / train_batch_gen in the engine's dataflow.  Same call signatures as MRGANOracle."""
 
@@ -369,7 +409,78 @@ class MRGANMirror(object):
         self.sigmas = sigmas
         self.uw = unlabeled_weight
         self.quantize = quantize
-        self.q = {None: _ident, 'bf16': bf16_round}[quantize]
+        self.q = {None: _ident, 'bf16': bf16_round, 'fp8': bf16_round}[quantize]
+        # fp8: the discriminator's dense products take e4m3 activations / weights and e5m2 gradients (gemm_fp8.hip); the
+        # generator, the loss head and predict_logits stay in the bf16 dataflow
+        self.fp8 = quantize == 'fp8'
+        if self.fp8:
+            self.slots = Fp8Slots()
+            self.cal = [False, False]
+            for _ in range(2):                       # mrgan_set_weights: the first pass only measures max |w|
+                self._refresh_w8()
+                self.slots.update()
+
+    # ---- fp8 mode ----------------------------------------------------------------------------------------
+    def _refresh_w8(self):
+        nl = len(self.d) // 2
+        self.w8 = [self.slots.quant(bf16_round(self.d[2 * l]), ('w', l), 'e4m3') for l in range(nl - 1)]
+
+    def _disc_fwd8(self, xin0, noise, kind):
+        """one segment through dense 1..5 with e4m3 operands; xin0 = the bf16 noisy input rows"""
+        q, sl = self.q, self.slots
+        nl = len(self.d) // 2
+        xin, masks = [sl.quant(xin0, ('x', kind, 0), 'e4m3')], []
+        a = None
+        for l in range(nl - 1):
+            a = relu(xin[l] @ self.w8[l] + self.d[2 * l + 1])
+            masks.append(a > 0)
+            if l < nl - 2:
+                xin.append(sl.quant(q(a + np.asarray(self.sigmas[l + 1], a.dtype) * noise[l + 1]), ('x', kind, l + 1), 'e4m3'))
+        return dict(xin=xin, masks=masks, feat=a, feat_q=q(a))
+
+    def _disc_bwd8(self, c, dpre_top, kind, to_input=False):
+        """dX chain with e5m2 gradients; returns the dequantised g8[l], the bias sums, and (to_input) d loss / d x"""
+        q, sl = self.q, self.slots
+        nl = len(self.d) // 2
+        dpre, db = [None] * (nl - 1), [None] * (nl - 1)
+        dpre[nl - 2] = sl.quant(dpre_top, ('g', kind, nl - 2), 'e5m2')
+        for l in range(nl - 2, 0, -1):
+            v = (dpre[l] @ self.w8[l].T) * c['masks'][l - 1]
+            db[l - 1] = v.sum(axis=0)
+            dpre[l - 1] = sl.quant(q(v), ('g', kind, l - 1), 'e5m2')
+        dx = dpre[0] @ self.w8[0].T if to_input else None
+        return dpre, db, dx
+
+    def _disc_grads8(self, x_lab, labels, x_unl, z, n_lab, n_unl, n_fake):
+        q = self.q
+        nl = len(self.d) // 2
+        xf, _ = self._gen_fwd(z, n_fake[0])
+        segs = [self._disc_fwd8(self._stage(x_lab, n_lab[0]), n_lab, 0), self._disc_fwd8(self._stage(x_unl, n_unl[0]), n_unl, 0),
+                self._disc_fwd8(xf, n_fake, 0)]
+        W6, b6 = self.d[-2], self.d[-1]
+        logits = [c['feat_q'] @ W6 + b6 for c in segs]
+        out = disc_losses(logits[0], labels, logits[1], logits[2])
+        dls = disc_loss_grads(logits[0], labels, logits[1], logits[2], self.uw)
+        grads = [np.zeros_like(p) for p in self.d]
+        for c, dl in zip(segs, dls):
+            grads[-2] += c['feat_q'].T @ dl
+            grads[-1] += dl.sum(axis=0)
+            dp = (dl @ W6.T) * (c['feat_q'] > 0)
+            grads[2 * (nl - 2) + 1] += dp.sum(axis=0)
+            dpre, db, _ = self._disc_bwd8(c, q(dp), 0)
+            for l in range(nl - 1):
+                grads[2 * l] += c['xin'][l].T @ dpre[l]
+                if l < nl - 2:
+                    grads[2 * l + 1] += db[l]
+        return out, grads, dict(l_lab=logits[0], l_unl=logits[1], l_fake=logits[2])
+
+    def _calibrate(self, kind, fn):
+        """first sub-step of a kind: dry passes settle the delayed scales (mrgan_disc_step / mrgan_gen_step)"""
+        if self.fp8 and not self.cal[kind]:
+            for _ in range(FP8_DRY_PASSES):
+                fn()
+                self.slots.update()
+            self.cal[kind] = True
 
     # ---- generator forward (engine: stage z -> G1+stats -> bn_apply -> G2 -> G3(+noise)) ----
     def _gen_fwd(self, z, n0):
@@ -422,6 +533,10 @@ class MRGANMirror(object):
         return dpre, db
 
     def disc_grads(self, x_lab, labels, x_unl, z, n_lab, n_unl, n_fake):
+        if self.fp8:
+            a = (x_lab, labels, x_unl, z, n_lab, n_unl, n_fake)
+            self._calibrate(0, lambda: self._disc_grads8(*a))
+            return self._disc_grads8(*a)
         q = self.q
         nl = len(self.d) // 2
         xf, _ = self._gen_fwd(z, n_fake[0])
@@ -447,6 +562,9 @@ class MRGANMirror(object):
     def disc_step(self, *a, **k):
         out, grads, _ = self.disc_grads(*a, **k)
         self.adam.apply(self.d, grads, 'd')
+        if self.fp8:                                   # D_ADAM: refresh the fp8 weight copies, then the scale update
+            self._refresh_w8()
+            self.slots.update()
         return out
 
     # supervised step of the NN baseline in the engine's dataflow (engine.hip sup_step)
@@ -475,17 +593,29 @@ class MRGANMirror(object):
         return out
 
     def gen_grads(self, x_unl, z, n_fake, n_real):
+        if self.fp8:
+            self._calibrate(1, lambda: self._gen_grads(x_unl, z, n_fake, n_real))
+        return self._gen_grads(x_unl, z, n_fake, n_real)
+
+    def _gen_grads(self, x_unl, z, n_fake, n_real):
         q = self.q
         W1, b1, gamma, beta, W2, b2, W3, b3 = self.g
         xf, gc = self._gen_fwd(z, n_fake[0])
-        cf = self._disc_fwd(xf, n_fake)
-        cr = self._disc_fwd(self._stage(x_unl, n_real[0]), n_real)
+        if self.fp8:
+            cf = self._disc_fwd8(xf, n_fake, 1)
+            cr = self._disc_fwd8(self._stage(x_unl, n_real[0]), n_real, 1)
+        else:
+            cf = self._disc_fwd(xf, n_fake)
+            cr = self._disc_fwd(self._stage(x_unl, n_real[0]), n_real)
         B, J = cf['feat'].shape
         diff = cf['feat'].sum(axis=0) / B - cr['feat'].sum(axis=0) / B          # moments of the unrounded features
         loss = np.mean(diff * diff)
         gj = (2.0 / (J * B)) * diff
-        dpre, _ = self._disc_bwd(cf, q(np.where(cf['masks'][-1], gj, 0.0)), False)
-        v = dpre[0] @ q(self.d[0]).T                                              # d loss / d x_fake (noise is additive)
+        if self.fp8:
+            _, _, v = self._disc_bwd8(cf, q(np.where(cf['masks'][-1], gj, 0.0)), 1, to_input=True)
+        else:
+            dpre, _ = self._disc_bwd(cf, q(np.where(cf['masks'][-1], gj, 0.0)), False)
+            v = dpre[0] @ q(self.d[0]).T                                          # d loss / d x_fake (noise is additive)
         db3 = v.sum(axis=0)
         dxf = q(v)
         dW3 = gc['h2q'].T @ dxf
@@ -507,6 +637,8 @@ class MRGANMirror(object):
     def gen_step(self, *a, **k):
         loss, grads, _ = self.gen_grads(*a, **k)
         self.adam.apply(self.g, grads, 'g')
+        if self.fp8:
+            self.slots.update()
         return loss
 
     def predict_logits(self, x):

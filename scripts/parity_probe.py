@@ -1,5 +1,5 @@
 """Per-tensor gradient error of the engine against the oracle mirror and the fp64 oracle (diagnostic).
-usage: python scripts/parity_probe.py D B [dtype 0|1]"""
+usage: python scripts/parity_probe.py D B [dtype 0|1|2]      (2 = fp8)"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np
@@ -13,7 +13,7 @@ dtype = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 DEV = "cuda:0"
 t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dt)
 case = Case(D=D, B=B, steps=1)
-mir = O.MRGANMirror(case.g0, case.d0, quantize='bf16' if dtype == 1 else None)
+mir = O.MRGANMirror(case.g0, case.d0, quantize={0: None, 1: 'bf16', 2: 'fp8'}[dtype])
 orc = O.MRGANOracle(case.g0, case.d0)
 (ll, lu, err), gd_m, _ = mir.disc_grads(**case.disc_inputs(0, 0))
 _, gd_o, _ = orc.disc_grads(**case.disc_inputs(0, 0))
@@ -30,6 +30,10 @@ for i, (a, m, o) in enumerate(zip(eng.get_slot(E.NET_D, 2), gd_m, gd_o)):
 out = eng.disc_step(da, E.D_ADAM, E.D_ADAM)
 print("losses engine", out, "mirror", (ll, lu, err))
 mir.adam.apply(mir.d, gd_m, 'd')
+if dtype == 2:                      # what mrgan_set_weights does to the fp8 weight copies (two passes)
+    for _ in range(2):
+        mir._refresh_w8(); mir.slots.update()
+    print("fp8 scales (mirror):", {k: float(v) for k, v in sorted(mir.slots.scale.items(), key=str)})
 orc.d = [p.copy() for p in mir.d]
 eng.set_weights(E.NET_D, [p.astype(np.float32) for p in mir.d])
 loss, gg_m, _ = mir.gen_grads(**case.gen_inputs(0, 1))

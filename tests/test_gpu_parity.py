@@ -76,9 +76,9 @@ def test_gemm_products(dtype, tol, m, n, k):
         assert rel_err(dw, x64.T @ dy64) < tol, splits
 
 
-@pytest.mark.parametrize("m,n,k", [(200, 192, 256), (1024, 512, 1024)])
-def test_fp8_forward_product_matches_e4m3_quantised_reference(m, n, k):
-    """gemm_fp8.hip (v_mfma_f32_32x32x16_fp8_fp8): the product of the e4m3-quantised operands, exactly -- the reference
+@pytest.mark.parametrize("m,n,k,cfg", [(200, 192, 256, -1), (1024, 512, 1024, 1), (1000, 512, 1024, 3), (8192, 4096, 4096, -1)])
+def test_fp8_forward_product_matches_e4m3_quantised_reference(m, n, k, cfg):
+    """gemm_fp8.hip (v_mfma_scale_f32_32x32x64_f8f6f4, 128x128 and 256x256 blocks): the product of the e4m3-quantised operands, exactly -- the reference
     quantises the same scaled fp32 inputs with torch.float8_e4m3fn (OCP, round to nearest even) and multiplies in fp64, so
     what is left is fp32 accumulation and the bf16 rounding of the output.  Asymmetric operands, ragged M."""
     from mr_gan_amd import engine as E
@@ -90,8 +90,8 @@ def test_fp8_forward_product_matches_e4m3_quantised_reference(m, n, k):
     sa, sb = pow2(x), pow2(w)
     q = lambda v, sc: torch.from_numpy(v * np.float32(sc)).to(torch.float8_e4m3fn).to(torch.float64).numpy() / sc
     for act, f in ((0, lambda v: v), (1, lambda v: np.maximum(v, 0))):
-        got, _ = E.debug_gemm_fp8(_t(x), _t(w), _t(b), act=act, scale_a=sa, scale_b=sb)
-        want = f(q(x, sa) @ q(w, sb) + b)
+        got, _ = E.debug_gemm_fp8(_t(x), _t(w), _t(b), act=act, scale_a=sa, scale_b=sb, kc_cfg=cfg)
+        want = f((torch.from_numpy(q(x, sa)).to(DEV) @ torch.from_numpy(q(w, sb)).to(DEV)).cpu().numpy() + b)
         assert rel_err(got.cpu().numpy(), want) < 6e-3, act             # bf16 output rounding (2^-9 of the largest element)
         assert rel_err(got.cpu().numpy(), f(x.astype(np.float64) @ w + b)) < 0.1     # and fp8 itself stays a ~3 % perturbation
 
@@ -352,7 +352,7 @@ def test_bf16_steps_match_bf16_mirror():
     eng.close()
 
 
-def _grad_parity(D, B, dtype, quantize, tol, tol_loss, d_hidden=None, g_hidden=None, eval_first=True, frac=0.6):
+def _grad_parity(D, B, dtype, quantize, tol, tol_loss, d_hidden=None, g_hidden=None, eval_first=True, frac=0.6, loose=(0.995, 0.98, 0.25)):
     """One D sub-step and one G sub-step in flat-gradient mode: all 20 gradient tensors and the four losses.
 
     fp32 engine (quantize None): against the fp64 restatement at `tol`.
@@ -389,14 +389,18 @@ def _grad_parity(D, B, dtype, quantize, tol, tol_loss, d_hidden=None, g_hidden=N
             report.append("%s%-2d %.1e %.1e %.1e" % (name, i, em, eo, emo))
             assert em < max(tol, frac * emo), (name + " vs mirror", i, em, emo)
             if quantize:      # loose, vs fp64: ten chained contractions on bf16 operands keep the gradient's direction
-                assert cosine(a, o) > cos_min and eo < 0.25, (name + " vs fp64", i, cosine(a, o), eo)
+                assert cosine(a, o) > cos_min and eo < loose[2], (name + " vs fp64", i, cosine(a, o), eo)
 
-    check("dD", eng.get_slot(E.NET_D, 2), gd_m, gd_o, 0.995)
+    check("dD", eng.get_slot(E.NET_D, 2), gd_m, gd_o, loose[0])
     out = eng.disc_step(da, E.D_ADAM, E.D_ADAM)
     np.testing.assert_allclose(out[:2], (ll, lu), rtol=tol_loss, atol=tol_loss * 0.1)
-    assert abs(out[2] - err) <= (1.01 / B if quantize else 1e-6)
+    assert abs(out[2] - err) <= ((4.01 if quantize == 'fp8' else 1.01) / B if quantize else 1e-6)      # an argmax or two may flip
     # the G sub-step sees the D network AFTER its update: give engine, mirror and oracle the same updated weights
     mir.adam.apply(mir.d, gd_m, 'd')
+    if quantize == 'fp8':           # mrgan_set_weights below re-measures the fp8 weight copies in two passes; so does the mirror
+        for _ in range(2):
+            mir._refresh_w8()
+            mir.slots.update()
     orc.d = [p.copy() for p in mir.d]
     orc.adam.iterations = 1
     eng.set_weights(E.NET_D, [p.astype(np.float32) for p in mir.d])
@@ -404,7 +408,7 @@ def _grad_parity(D, B, dtype, quantize, tol, tol_loss, d_hidden=None, g_hidden=N
     _, gg_o, _ = orc.gen_grads(**case.gen_inputs(0, 1))
     ga = E.Engine.gen_args(_t(case.x_unl2[0]), _t(case.z2[0]))
     eng.gen_step(ga, E.G_GEN, E.G_TAIL, want_outputs=False)
-    check("dG", eng.get_slot(E.NET_G, 2), gg_m, gg_o, 0.98)
+    check("dG", eng.get_slot(E.NET_G, 2), gg_m, gg_o, loose[1])
     lg = eng.gen_step(ga, E.G_ADAM, E.G_ADAM)
     assert abs(lg - loss) < 5 * tol_loss * abs(loss) + 1e-12, (lg, loss)
     eng.close()
@@ -456,6 +460,77 @@ def test_wide_stack_bf16_matches_bf16_mirror():
     The layer widths are literals in the reference (mr_gan.py:111-128); mrgan_config generalises them."""
     # (reductions of length 4096: the fp32 accumulation error, hence the residual against the mirror, is larger: frac 0.85)
     _grad_parity(512, 1024, 1, 'bf16', tol=3e-3, tol_loss=5e-4, d_hidden=(4096,) * 5, g_hidden=(4096,) * 2, eval_first=False, frac=0.85)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp8 mode (BASELINE configs[4]): the discriminator's products on the fp8 matrix cores, against the oracle's fp8 mirror
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,B,hidden", [(400, 256, None),          # reference widths (padded to multiples of 128), 128x128 blocks
+                                        (200, 50, None),           # ragged batch: the transposed copies keep zero padding rows
+                                        (512, 1024, 2048)])        # wide stack, K = 2048 reductions
+def test_fp8_gradients_match_fp8_mirror(D, B, hidden):
+    """One D and one G sub-step with MRGAN_FP8 (gemm_fp8.hip: e4m3 activations / weights, e5m2 gradients, delayed power-of-two
+    scales settled by the dry passes of the first sub-step) against MRGANMirror(quantize='fp8'), which rounds to fp8 exactly
+    where the engine stores fp8.  Same bound as the bf16 mode: err(engine, mirror) < max(tol, frac * err(mirror, fp64)) --
+    what is left between engine and mirror is fp32-vs-fp64 accumulation flipping individual fp8 / bf16 roundings, a fraction
+    of what fp8 itself does to the gradients (measured ~0.25: scripts/parity_probe.py D B 2).  Loose bounds against fp64 say
+    what fp8 costs: gradient direction cosine > 0.9."""
+    kw = dict(d_hidden=(hidden,) * 5, g_hidden=(hidden,) * 2) if hidden else {}
+    _grad_parity(D, B, 2, 'fp8', tol=5e-3, tol_loss=2e-3, eval_first=hidden is None, frac=0.6 if hidden is None else 0.85,
+                 loose=(0.9, 0.8, 0.6), **kw)
+
+
+def test_fp8_steps_match_fp8_mirror():
+    """three (D, G) pairs in fp8 mode: losses and weights against the fp8 mirror's trajectory (delayed scales included)"""
+    case = Case(D=400, B=128, steps=3)
+    ref = case.run_oracle()
+    mir = case.run_oracle(mirror=True, quantize='fp8')
+    eng = _engine(400, 128, 2)
+    _load(eng, case)
+    got = _run_engine(eng, case)
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-12)
+    for t in range(case.steps):
+        for k in range(2):
+            slack = 0.0 if t == 0 else max(2e-2, 2.0 * rel(mir['disc'][t][k], ref['disc'][t][k]))
+            assert rel(got['disc'][t][k], mir['disc'][t][k]) < max(2e-3, slack), (t, k, got['disc'][t], mir['disc'][t], ref['disc'][t])
+        assert abs(got['disc'][t][2] - mir['disc'][t][2]) <= 3.01 / 128
+        assert rel(got['gen'][t], mir['gen'][t]) < max(5e-3 if t == 0 else 5e-2, (0.6 if t == 0 else 2.0) * rel(mir['gen'][t], ref['gen'][t])), (t, got['gen'][t], mir['gen'][t], ref['gen'][t])
+    for name, ws, wm, wr_, w0 in (("D", got['d'], mir['d'], ref['d'], case.d0), ("G", got['g'], mir['g'], ref['g'], case.g0)):
+        for i, (w, wm_i, wr, wi) in enumerate(zip(ws, wm, wr_, w0)):
+            em, eo, emo = update_rel_err(w, wm_i, wi), update_rel_err(w, wr, wi), update_rel_err(wm_i, wr, wi)
+            # after three Adam updates (early steps ~ lr * sign(g)) engine and mirror have each drifted from fp64 by about the
+            # same amount; the per-step gradient tests above are the tight ones
+            assert em < max(0.15, 1.2 * emo), (name, i, em, emo)
+            assert eo < 0.8, (name, i, eo)
+    assert rel_err(got['logits'], mir['logits']) < max(5e-3, 1.0 * rel_err(mir['logits'], ref['logits']))
+    assert eng.get_iterations() == 2 * case.steps
+    eng.close()
+
+
+def test_fp8_large_tiles_equal_small_tiles():
+    """the 256x256-block instantiations of the fp8 kernel (selected by themselves only at the full configs[4] size) against the
+    128x128 ones on the same step: the reduction order per element is the same, so the gradients agree to rounding noise"""
+    from mr_gan_amd import engine as E
+    case = Case(D=512, B=1024, steps=1, device_z=True, d_hidden=(1024,) * 5, g_hidden=(512, 512))
+    res = []
+    for cfg in (1, 3):
+        eng = _engine(512, 1024, 2, flags=E.FLAG_FLAT_GRADS, d_hidden=(1024,) * 5, g_hidden=(512, 512))
+        eng.set_tuning(E.TUNE_KC_CFG, cfg)
+        _load(eng, case)
+        da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]))
+        eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
+        gd = eng.get_slot(E.NET_D, 2)
+        out = eng.disc_step(da, E.D_ADAM, E.D_ADAM)
+        ga = E.Engine.gen_args(_t(case.x_unl2[0]))
+        eng.gen_step(ga, E.G_GEN, E.G_TAIL, want_outputs=False)
+        res.append((gd, out, eng.get_slot(E.NET_G, 2)))
+        eng.close()
+    (gd1, out1, gg1), (gd3, out3, gg3) = res
+    np.testing.assert_allclose(out1, out3, rtol=1e-5, atol=1e-6)
+    for i, (a, b) in enumerate(zip(gd1, gd3)):
+        assert rel_err(a, b) < 1e-5, ("dD", i, rel_err(a, b))
+    for i, (a, b) in enumerate(zip(gg1, gg3)):
+        assert rel_err(a, b) < 1e-3, ("dG", i, rel_err(a, b))       # (the bf16 generator kernels change their tile with the knob too)
 
 
 def test_wide_stack_fp32_matches_oracle():

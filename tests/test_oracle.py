@@ -254,3 +254,49 @@ def test_supervised_step_grads_match_autograd_and_mirror():
     # first Adam step of the Keras defaults moves every weight by lr (bias-corrected m / sqrt(v) = sign(g))
     moved = np.abs(a.d[0] - d[0])
     assert a.adam.iterations == 2 and moved.max() < 2.01 * O.NN_ADAM_LR
+
+
+def test_fp8_rounding_matches_torch_float8_and_scale_rule():
+    """fp8_round restates OCP e4m3 / e5m2 round-to-nearest-even with subnormals (what gemm_fp8.hip's v_cvt_pk_fp8_f32 /
+    v_cvt_pk_bf8_f32 produce from clamped inputs): pinned against torch's float8 conversions.  Fp8Slots.update restates
+    fp8_update_scales_kernel: scale = 2^floor(log2(target / amax)), from the fp32 quotient's exponent."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(50000) * 10.0 ** rng.uniform(-7, 4, 50000),
+                        [0.0, 448.0, 449.0, -1e9, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 57344.0, 2.0 ** -16, 2.0 ** -17, 3 * 2.0 ** -17]]).astype(np.float32)
+    for fmt, tdt in (('e4m3', torch.float8_e4m3fn), ('e5m2', torch.float8_e5m2)):
+        lim = O.FP8_FORMATS[fmt][2]
+        want = torch.from_numpy(np.clip(x, -lim, lim)).to(tdt).to(torch.float64).numpy()
+        np.testing.assert_array_equal(O.fp8_round(x, fmt), want)
+    sl = O.Fp8Slots()
+    v = O.bf16_round(rng.standard_normal((64, 64)) * 3.7)
+    sl.quant(v, 'a', 'e4m3')
+    sl.quant(v * 1e-5, 'g', 'e5m2')
+    sl.update()
+    amax = np.abs(v).max()
+    assert sl.scale['a'] == 2.0 ** np.floor(np.log2(224.0 / amax)) and sl.scale['g'] == 2.0 ** np.floor(np.log2(28672.0 / (amax * 1e-5)))
+    assert amax * sl.scale['a'] <= 224.0 < 2 * amax * sl.scale['a']
+    q = sl.quant(v, 'a', 'e4m3')
+    assert np.abs(q - v).max() <= 2.0 ** -4 * amax                   # 3 mantissa bits: half an ulp of the largest binade
+    sl.update(); sl.update()                                           # a pass that wrote nothing keeps the scale
+    assert sl.scale['a'] == 2.0 ** np.floor(np.log2(224.0 / amax))
+
+
+def test_fp8_mirror_calibrates_and_stays_close_to_fp64_oracle():
+    """MRGANMirror(quantize='fp8'): the dry passes of the first sub-steps must leave every gradient tensor well scaled (no
+    layer flushed to zero by the e5m2 range), and fp8 keeps the gradient directions (cosine > 0.9)"""
+    g, d, x_lab, labels, x_unl, z, n1, n2, n3 = _rand_problem(D=40, B=32, seed=4)
+    a, b = O.MRGANOracle(g, d), O.MRGANMirror(g, d, quantize='fp8')
+    (_, ga, _), (_, gb, _) = a.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3), b.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3)
+    assert b.cal == [True, False] and all(('g', 0, l) in b.slots.scale and b.slots.scale[('g', 0, l)] > 1e3 for l in range(5))
+    for u, v in zip(ga, gb):
+        cos = float((u * v).sum() / np.sqrt((u * u).sum() * (v * v).sum()))
+        assert cos > 0.9 and np.abs(v).max() > 0
+    (la, ha, _), (lb, hb, _) = a.gen_grads(x_unl, z, n1, n2), b.gen_grads(x_unl, z, n1, n2)
+    assert b.cal == [True, True] and abs(la - lb) < 0.1 * abs(la)
+    for u, v in zip(ha, hb):
+        assert float((u * v).sum() / np.sqrt((u * u).sum() * (v * v).sum())) > 0.8
+    # two dry-calibrated mirrors are deterministic
+    c = O.MRGANMirror(g, d, quantize='fp8')
+    _, gc, _ = c.disc_grads(x_lab, labels, x_unl, z, n1, n2, n3)
+    for u, v in zip(gb, gc):
+        np.testing.assert_array_equal(u, v)
