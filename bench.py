@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.29 TB/s measured by a float4 copy), same guide
 
 
@@ -180,7 +180,9 @@ def main():
                     help="0 = the reference's layer widths (mr_gan.py:111-128); W = BASELINE configs[4]'s wide stack: five "
                          "discriminator layers and two generator layers of width W")
     ap.add_argument("--labeled-per-class", type=int, default=100)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8: the discriminator's dense products on the fp8 matrix cores (BASELINE configs[4] asks for it with "
+                         "--hidden 4096 --batch 8192); generator / loss head stay bf16")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: every rank takes GLOBAL / N rows of each stream (default 0: --batch rows per rank, weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -229,7 +231,7 @@ def main():
         cfg.g_hidden[0], cfg.g_hidden[1] = g_hidden
         for i, w in enumerate(d_hidden):
             cfg.d_hidden[i] = w
-    cfg.dtype = E.BF16 if args.dtype == "bf16" else E.F32
+    cfg.dtype = {"bf16": E.BF16, "f32": E.F32, "fp8": E.FP8}[args.dtype]
     cfg.seed = 1
     cfg.rank, cfg.world = rank, world
     use_dp = world > 1 or args.force_dp
@@ -318,8 +320,13 @@ def main():
     ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)                       # FLOP per byte at which the two roofs meet (312 for bf16)
     P = float(args.profile_steps)
 
-    def line(ms, launches, flops, nbytes):
+    def peak_of(k):
+        """dense MFMA peak of the arithmetic a kernel computes in (the fp8 mode keeps bf16 kernels for the generator)"""
+        return PEAK_TFLOPS["fp8"] if k.startswith("gemm_fp8") else (PEAK_TFLOPS["bf16"] if args.dtype == "fp8" else PEAK_TFLOPS[args.dtype])
+
+    def line(ms, launches, flops, nbytes, peak=peak):
         """roofline entry of one kernel (or family) from its live-measured time and its ALGORITHMIC work"""
+        ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
         sec = 1e-3 * ms
         ai = flops / nbytes if nbytes > 0 else None
         d = {"ms_per_step": round(ms / P, 4), "launches_per_step": launches / P,
@@ -335,6 +342,12 @@ def main():
         return d
 
     def family(k):
+        if k.startswith("gemm_fp8_kc_kernel<0"):
+            return "fp8_forward"
+        if k.startswith("gemm_fp8_kc_kernel<1"):
+            return "fp8_input_gradient"
+        if k.startswith("gemm_fp8_kc_kernel<2"):
+            return "fp8_weight_gradient"
         if k.startswith("gemm_bf16_kc_kernel<0") or k.startswith("gemm_f32_kernel<0"):
             return "kc_forward"
         if k.startswith("gemm_bf16_kc_kernel<1") or k.startswith("gemm_f32_kernel<1"):
@@ -344,9 +357,10 @@ def main():
         if k.startswith("chain_kernel"):
             return "row_block_chain"
         return "elementwise"
-    fams = {}
+    fams, fam_peak = {}, {}
     for k, v in prof.items():
         f = fams.setdefault(family(k), [0.0, 0, 0.0, 0.0])
+        fam_peak[family(k)] = peak_of(k)
         for i in range(4):
             f[i] += v[i]
     # dominant kernel = the instantiation with the largest share of device time in the profiled pass
@@ -364,14 +378,14 @@ def main():
         if row:
             traffic = {"hbm_bytes_per_launch": round(row["hbm_bytes_per_launch"]), "source": "profiles/r02_traffic.json",
                        "measured_at_commit": tj.get("commit")}
-    roofline = line(*prof[dom])
+    roofline = line(*prof[dom], peak=peak_of(dom))
     roofline.update({
         "kernel": dom, "traffic": traffic,
         "timing": "hipEvent (start, stop) pairs stamped at each kernel's begin and end on the launch stream "
                   "(hipExtLaunchKernelGGL inside the library), profiled pass of %d steps after the timed region" % args.profile_steps,
         "avg_launch_us": round(1e3 * prof[dom][0] / max(prof[dom][1], 1), 2),
-        "bound_rule": "mfma if algorithmic FLOP per algorithmic byte >= %.0f (= %.0f TFLOP/s / %.0f GB/s), else hbm" % (ridge, peak, PEAK_HBM_GBS),
-        "families": {k: line(*v) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
+        "bound_rule": "mfma if algorithmic FLOP per algorithmic byte >= peak TFLOP/s / %.0f GB/s of the kernel's arithmetic (312 for bf16, 625 for fp8), else hbm" % PEAK_HBM_GBS,
+        "families": {k: line(*v, peak=fam_peak[k]) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
         "step": {"algorithmic_gflop": round(fl["total"] / 1e9, 2), "achieved": round(fl["total"] / (elapsed / args.steps) / 1e12, 2),
                  "peak": peak, "unit": "TFLOP/s", "frac": round(fl["total"] / (elapsed / args.steps) / 1e12 / peak, 4),
                  "launches": sum(v[1] for v in prof.values()) / P,

@@ -223,36 +223,55 @@ __global__ void to_fp8_kernel(const float* src, long lds_, unsigned char* dst, l
     else dst[(long)r * ldd + c] = (unsigned char)(w & 0xFF);
 }
 
-// bf16 [nb][rows][ld] -> fp8 (row-major and / or transposed) of v * slot->scale, 64 x 64 tile per block; max |v| -> slot
+// bf16 [nb][rows][ld] -> fp8 (row-major and / or transposed) of v * slot->scale; max |v| -> slot.
+// Block = 256 rows x 64 columns: the transposed copy leaves through an LDS byte tile (row pitch 65: conflict-free in both
+// directions) so that every transposed row gets 256 contiguous bytes per block -- 16-byte pieces scattered at the transposed
+// pitch (a multiple of 8 KiB) ran at a seventh of this kernel's bandwidth.
+constexpr int Q8_ROWS = 256, Q8_PITCH = 65;
 template <int FMT>
 __global__ __launch_bounds__(256) void quant8_kernel(const Quant8Args a) {
-    __shared__ __bf16 tl[64][72];
+    __shared__ unsigned char tq[Q8_ROWS * Q8_PITCH];
     const int t = threadIdx.x, batch = blockIdx.z;
-    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    const int row0 = blockIdx.y * Q8_ROWS, col0 = blockIdx.x * 64;
     const float qs = a.slot->scale;
     const __bf16* src = a.src + (long)batch * a.src_bs;
-    const int r = t >> 2, cc = (t & 3) * 16;
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = 0.f;
-    if (row0 + r < a.rows) {
-        const bf16x8 lo = *(const bf16x8*)(src + (long)(row0 + r) * a.ld + col0 + cc), hi = *(const bf16x8*)(src + (long)(row0 + r) * a.ld + col0 + cc + 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] = (float)lo[i]; v[8 + i] = (float)hi[i]; }
-    }
+    const int cc = (t & 3) * 16;
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
-    if (a.dst) *(u32x4*)(a.dst + (long)batch * a.dst_bs + (long)(row0 + r) * a.ldd + col0 + cc) = pack16<FMT>(v, qs);
+    for (int u = 0; u < Q8_ROWS / 64; ++u) {
+        const int r = (t >> 2) + 64 * u;
+        if (row0 + r >= a.prow) break;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
+        if (row0 + r < a.rows) {
+            const bf16x8 lo = *(const bf16x8*)(src + (long)(row0 + r) * a.ld + col0 + cc), hi = *(const bf16x8*)(src + (long)(row0 + r) * a.ld + col0 + cc + 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] = (float)lo[i]; v[8 + i] = (float)hi[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+        const u32x4 w = pack16<FMT>(v, qs);
+        if (a.dst) *(u32x4*)(a.dst + (long)batch * a.dst_bs + (long)(row0 + r) * a.ldd + col0 + cc) = w;
+        if (a.dstt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tq[r * Q8_PITCH + cc + i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+        }
+    }
     if (a.dstt) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tl[r][cc + i] = (__bf16)v[i];
         __syncthreads();
-        const int col = t & 63, r0 = (t >> 6) * 16;
-        float w[16];
+        // 16 lanes cover the 256 rows of one column (16 bytes each): 256 contiguous bytes of the transposed row
+        const int rg = t & 15;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = (float)tl[r0 + i][col];
-        *(u32x4*)(a.dstt + (long)(col0 + col) * a.lddt + (long)batch * a.dstt_bs + row0 + r0) = pack16<FMT>(w, qs);
+        for (int u = 0; u < 4; ++u) {
+            const int col = (t >> 4) + 16 * u, r0 = rg * 16;
+            if (row0 + r0 < a.prow) {
+                u32x4 w = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int i = 0; i < 16; ++i) w[i >> 2] |= (uint32_t)tq[(r0 + i) * Q8_PITCH + col] << (8 * (i & 3));
+                *(u32x4*)(a.dstt + (long)(col0 + col) * a.lddt + (long)batch * a.dstt_bs + row0 + r0) = w;
+            }
+        }
     }
     amax_commit(a.slot, amax);
 }
@@ -315,7 +334,7 @@ int launch_quant8(const Quant8Args& a, hipStream_t s) {
     if ((a.cols % 64) || (a.prow % 64) || (a.ld % 8) || !a.slot || a.nb < 1) return -3;
     if (a.dst && (a.ldd % 16)) return -3;
     if (a.dstt && ((a.lddt % 16) || (a.dstt_bs % 16))) return -3;
-    const dim3 grid(a.cols / 64, a.prow / 64, a.nb);
+    const dim3 grid(a.cols / 64, ceil_div(a.prow, Q8_ROWS), a.nb);
     if (a.fmt == FP8_E5M2) MRGAN_LAUNCH(quant8_kernel<FP8_E5M2>, grid, dim3(256), 0, s, a);
     else MRGAN_LAUNCH(quant8_kernel<FP8_E4M3>, grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
