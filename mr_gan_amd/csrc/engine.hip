@@ -1676,7 +1676,15 @@ int mrgan_debug_gemm_fp8(int m, int n, int k, const float* a, const float* b, co
     g.A = ta; g.a_si = k; g.a_sk = 1; g.B = tb; g.b_sj = k; g.b_sk = 1;
     g.e.act = act; g.e.n_valid = n; g.e.bias = bias; g.e.out = to; g.e.ldo = n; g.e.acc_scale = 1.0f / (scale_a * scale_b);
     g.e.tune_kc_cfg = kc_cfg;
+#ifdef MRGAN_STAMPS
+    unsigned long long* stamps = nullptr;
+    HIPCHK(hipMalloc((void**)&stamps, 4096 * 4 * sizeof(unsigned long long)));
+    g.e.cs2 = (float*)stamps;
+#endif
     int r = launch_gemm_fp8(EPI_FWD, g, s);
+#ifdef MRGAN_STAMPS
+    HIPCHK(hipMemsetAsync(stamps, 0, 4096 * 4 * sizeof(unsigned long long), s));
+#endif
     if (!r && reps > 0 && avg_us) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1692,6 +1700,17 @@ int mrgan_debug_gemm_fp8(int m, int n, int k, const float* a, const float* b, co
     }
     if (!r && out) hipLaunchKernelGGL(to_f32_kernel<__bf16>, grid2d(m, n), dim3(256), 0, s, (const __bf16*)to, (long)n, out, (long)n, m, n);
     hipStreamSynchronize(s);
+#ifdef MRGAN_STAMPS
+    {
+        std::vector<unsigned long long> hs(4096 * 4);
+        hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        double cyc = 0, wait = 0, rt = 0, tiles = 0; int nb = 0;
+        for (int b = 0; b < 4096; ++b) if (hs[b * 4 + 3]) { cyc += hs[b * 4]; wait += hs[b * 4 + 1]; rt += hs[b * 4 + 2]; tiles += hs[b * 4 + 3]; ++nb; }
+        if (nb) fprintf(stderr, "[stamps] fp8 %dx%dx%d: blocks %d, tiles/block %.1f, k-loop cycles/tile %.0f (wait+barrier %.0f = %.1f %%), per k-tile %.0f, clock %.3f GHz\n",
+                        m, n, k, nb, tiles / nb, cyc / tiles, wait / tiles, 100.0 * wait / cyc, cyc / tiles / (k / 128), cyc / rt * 0.1);
+        hipFree(stamps);
+    }
+#endif
     hipFree(ta); hipFree(tb); hipFree(to);
     if (r) return fail(r, "debug_gemm_fp8: launch failed (%d)", r);
     return 0;

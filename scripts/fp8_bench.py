@@ -8,7 +8,7 @@ x = torch.randn(M, K, device="cuda:0"); w = torch.randn(K, N, device="cuda:0") /
 gf = 2.0 * M * N * K / 1e9
 for cfg in (1, 3):
     _, us8 = E.debug_gemm_fp8(x, w, None, act=1, scale_a=32.0, scale_b=2048.0, reps=20, kc_cfg=cfg)
-    print("fp8  e4m3 forward %d x %d x %d (tile cfg %d): %.1f us  %.0f TFLOP/s" % (M, N, K, cfg, us8, gf / us8))
+    print("fp8  e4m3 forward %d x %d x %d (tile cfg %d): %.1f us  %.0f TFLOP/s" % (M, N, K, cfg, us8, 1e3 * gf / us8))
 for cfg in (1, 2, 3):
     us = E.debug_gemm_time(4, 8192, N, K, 3, 1, reps=20, kc_cfg=cfg)
-    print("bf16 forward (plain relu, tile cfg %d): %.1f us  %.0f TFLOP/s" % (cfg, us, gf / us))
+    print("bf16 forward (plain relu, tile cfg %d): %.1f us  %.0f TFLOP/s" % (cfg, us, 1e3 * gf / us))
