@@ -613,8 +613,8 @@ def test_accuracy_parity_on_mreo_surrogate():
     The MREO data set is not available offline (README.md:7-11), so this runs SURVEY 8(d) config 1's surrogate at the real size
     (synthetic_mreo: N = 7200 = 6 classes x 12 objects x 100 trials, D = 1200 = force + temperature layout, 6-fold split 0 ->
     6000 training / 1200 test rows, batch 50, mr_gan.py:73-82), at 50 and at 500 labeled rows per class, through
-        (a) the HIP engine in fp32, (b) the HIP engine in bf16, (c) the CPU oracle in float32 numpy,
-    all three from the same initial weights, the same index streams (mr_gan.py:189-195) and the same z / GaussianNoise
+        (a) the HIP engine in fp32, (b) the HIP engine in bf16, (c) the CPU oracle in float32 numpy, (d) the HIP engine in fp8,
+    all from the same initial weights, the same index streams (mr_gan.py:189-195) and the same z / GaussianNoise
     streams (the engine's generator, restated in the oracle).  The class separation (sep = 0.5) is chosen so that the final
     error is small but not zero (0.3 - 1 %), i.e. the comparison is not vacuous.
     A single evaluation of one trajectory moves by +-0.3 % from epoch to epoch (GaussianNoise is active in training, and the
@@ -649,7 +649,7 @@ def test_accuracy_parity_on_mreo_surrogate():
                   for n_lab, (xl, yl) in probs.items()}
         err, last5 = {}, {}        # (last5: mean over the last ten epochs)
         for n_lab, (xl, yl) in probs.items():
-            for dt in ('float32', 'bfloat16'):
+            for dt in ('float32', 'bfloat16', 'fp8'):
                 m = MRGAN(Xtr.shape[1], batch_size=50, dtype=dt, seed=seed)
                 hist = m.fit(xl, yl, Xtr, epochs=epochs, validation_data=(Xte, yte), rng=np.random.RandomState(5))
                 err[(n_lab, dt)] = m.evaluate(Xte, yte)
@@ -673,6 +673,10 @@ def test_accuracy_parity_on_mreo_surrogate():
         assert max(e) < 0.05, (n_lab, e)                                    # everybody learned the task
         assert max(a) - min(a) <= 0.005 + 1e-9, (n_lab, "last-10 mean", a)   # north_star: +-0.5 % absolute
         assert max(e) - min(e) <= 0.01 + 1e-9, (n_lab, "final", e)
+        # the fp8 mode (e4m3 / e5m2 discriminator products, a different numerical path by design): same bounds against the
+        # three paths above
+        assert abs(last5[(n_lab, 'fp8')] - float(np.mean(a))) <= 0.005 + 1e-9, (n_lab, "fp8 last-10 mean", last5[(n_lab, 'fp8')], a)
+        assert err[(n_lab, 'fp8')] < 0.05 and abs(err[(n_lab, 'fp8')] - float(np.mean(e))) <= 0.01 + 1e-9, (n_lab, "fp8 final", err[(n_lab, 'fp8')], e)
 
 
 def test_graph_replay_equals_eager():
