@@ -148,4 +148,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
+// ---- fp8 (OCP e4m3 / e5m2) packing: four floats -> four bytes of v * qs, round to nearest even, saturating ----
+enum { FP8_E4M3 = 0, FP8_E5M2 = 1 };
+template <int FMT>
+__device__ __forceinline__ uint32_t fp8_pack4(float a, float b, float c, float d, float qs) {
+    constexpr float LIM = FMT == FP8_E5M2 ? 57344.f : 448.f;
+    a = fminf(fmaxf(a * qs, -LIM), LIM); b = fminf(fmaxf(b * qs, -LIM), LIM);
+    c = fminf(fmaxf(c * qs, -LIM), LIM); d = fminf(fmaxf(d * qs, -LIM), LIM);
+    int w;
+    if constexpr (FMT == FP8_E5M2) { w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true); }
+    else { w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true); }
+    return (uint32_t)w;
+}
+
 }  // namespace mrgan

@@ -26,7 +26,6 @@ enum { VAR_ACT_MASK = 3, VAR_NOISE = 4, VAR_MASK = 8, VAR_DYN = 64 };
 // one fp8 tensor's scaling state.  Delayed scaling: a pass stores with `scale` (from the amax of the previous pass) and
 // records its own max |v| (before scaling); fp8_update_scales_kernel turns that into the next pass's scale.
 struct Fp8Slot { uint32_t amax_bits; float scale, inv_scale; float target; };
-enum { FP8_E4M3 = 0, FP8_E5M2 = 1 };
 
 struct Epi {
     int act;                 // FWD: activation; DX: derivative applied (RELU mask / SOFTPLUS from h / LINEAR)
@@ -121,7 +120,11 @@ __device__ __forceinline__ void epilogue_prefetch(EpiPrefetch<MR, NR>& pf, const
 // STAGED: the block's output tile is first assembled in LDS (`tile`, [BM][bn] of T, the dead staging
 // buffers) and then written with coalesced 16-byte stores -- the accumulator layout holds one column
 // per lane, so direct stores would be 2-byte pieces at a row stride (store-issue bound).
-template <typename T, int EPI, int MR, int NR, int WM, bool STAGED = false, int VAR = VAR_DYN>
+// Q8 >= 0 (fp8 path, with STAGED): instead of the bf16 tile, `tile` receives the block's output as fp8 bytes of format Q8,
+// twice: row-major [BM][bn + 16] and transposed [bn][BM + 16] (BM = 32 WM MR).  A lane holds four consecutive rows of one
+// column per accumulator quad, i.e. exactly one dword of the transposed image; max |v| goes to e.qo.  Rows >= M are stored as
+// zeros.  The caller copies the two images out (gemm_fp8.hip copy_tile).
+template <typename T, int EPI, int MR, int NR, int WM, bool STAGED = false, int VAR = VAR_DYN, int Q8 = -1>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& g, int batch, int split,
                                          int tile_m, int row_blk, int col_blk, int wm, int wn, int lane,
                                          float* lds /* >= 2*WM*bn floats of scratch, disjoint from `tile` */,
@@ -175,6 +178,15 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             }
         }
 
+        float q8_scale = 1.f, q8_amax = 0.f;
+        float q8_cs[MR][NR];           // Q8 mode: column sums (CS_SUM) accumulated on the fly -- no `keep` copy of the tile
+        if constexpr (Q8 >= 0) {
+            q8_scale = e.qo->scale;
+#pragma unroll
+            for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NR; ++ni) q8_cs[mi][ni] = 0.f;
+        }
         // activated values for the column-sum pass below: ordinary registers, so a launch without column sums never
         // moves them back into the accumulator file
         float keep[MR][NR][16];
@@ -234,10 +246,33 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                             }
                             o = v;
                         }
-                        keep[mi][ni][r] = v;
+                        if constexpr (Q8 < 0) keep[mi][ni][r] = v;
                         if constexpr (!STAGED) { if (row < M && colin) out[(long)row * e.ldo + col] = Elem<T>::from_f32(o); }
                     }
-                    if constexpr (STAGED) {
+                    if constexpr (Q8 >= 0) {
+                        constexpr int BMT = WM * MR * 32;
+                        if (rsub + 32 > M) {                    // ragged last row block of the batch: rows >= M become zeros
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o4[j] = (r4 + j < M) ? o4[j] : 0.f;
+                        }
+                        q8_amax = fmaxf(q8_amax, fmaxf(fmaxf(fabsf(o4[0]), fabsf(o4[1])), fmaxf(fabsf(o4[2]), fabsf(o4[3]))));
+                        if constexpr (EPI == EPI_DX) q8_cs[mi][ni] += (o4[0] + o4[1]) + (o4[2] + o4[3]);      // bias-gradient sums (o == v)
+                        const uint32_t w = fp8_pack4<Q8>(o4[0], o4[1], o4[2], o4[3], q8_scale);
+                        unsigned char* q8r = (unsigned char*)tile;
+                        unsigned char* q8c = q8r + BMT * (bn + 16);
+                        const int rl = r4 - row_blk, cl = col - col_blk;
+                        *(uint32_t*)(q8c + cl * (BMT + 16) + rl) = w;
+                        // row-major image: 4 x 4 byte transpose inside each lane quad (4 neighbouring columns) by DPP
+                        // broadcasts + v_perm, then one dword per lane = row r4 + (lane & 3), columns of the quad
+                        const int kq = lane & 3;
+                        const uint32_t q0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x00, 0xF, 0xF, true);
+                        const uint32_t q1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x55, 0xF, 0xF, true);
+                        const uint32_t q2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xAA, 0xF, 0xF, true);
+                        const uint32_t q3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xFF, 0xF, 0xF, true);
+                        const uint32_t sel = (uint32_t)kq * 0x01010101u + 0x04000400u;           // bytes (k, 4 + k, k, 4 + k)
+                        const uint32_t lo = __builtin_amdgcn_perm(q1, q0, sel), hi = __builtin_amdgcn_perm(q3, q2, sel);
+                        *(uint32_t*)(q8r + (rl + kq) * (bn + 16) + (cl - kq)) = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                    } else if constexpr (STAGED) {
                         // rows r4 .. r4+3 of one column: convert in pairs (one v_cvt_pk per two values), store the halves
                         T* tp = tile + (r4 - row_blk) * bn + (col - col_blk);
                         if constexpr (sizeof(T) == 2) {
@@ -258,7 +293,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             }
         }
 
-        if constexpr (STAGED) {
+        if constexpr (Q8 >= 0) {
+            for (int o = 32; o > 0; o >>= 1) q8_amax = fmaxf(q8_amax, __shfl_xor(q8_amax, o, 64));
+            if (lane == 0 && q8_amax > 0.f) atomicMax(&e.qo->amax_bits, __float_as_uint(q8_amax));
+        } else if constexpr (STAGED) {
             typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
             constexpr int EPV = 16 / (int)sizeof(T);               // elements per 16-byte chunk
             const int chunks_per_row = bn / EPV, bm = WM * MR * 32;
@@ -270,7 +308,22 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             }
         }
 
-        if (e.cs_mode != CS_NONE) {
+        if constexpr (Q8 >= 0) {
+            static_assert(MR >= 2 && (MR % 2) == 0, "Q8 epilogue: each wave covers whole 64-row groups");
+            if (EPI == EPI_DX && e.cs_mode == CS_SUM) {
+                const long prow0 = (long)batch * g.tiles_m + (row_blk >> 6);
+#pragma unroll
+                for (int hh = 0; hh < MR / 2; ++hh)
+#pragma unroll
+                    for (int ni = 0; ni < NR; ++ni) {
+                        float s1 = q8_cs[2 * hh][ni] + q8_cs[2 * hh + 1][ni];
+                        s1 += __shfl_xor(s1, 32, 64);                     // lanes l and l ^ 32 hold the same column
+                        const int col = col_blk + (wn * NR + ni) * 32 + lc;
+                        const long pr = prow0 + wm * (MR / 2) + hh;
+                        if (lh == 0 && col < e.ldcs && row_blk + (wm * (MR / 2) + hh) * 64 < M) e.cs1[pr * e.ldcs + col] = s1;
+                    }
+            }
+        } else if (e.cs_mode != CS_NONE) {
             // column sums per 64-row half of the wave tile (MR >= 2) or of the whole 32-row wave tile
             constexpr int NH = MR >= 2 ? MR / 2 : 1, MH = MR >= 2 ? 2 : 1;
             float cs1[NH][NR], cs2[NH][NR];

@@ -36,74 +36,48 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
-// four floats -> four fp8 bytes of v * qs (round to nearest even, saturating at the format's largest finite value)
-template <int FMT>
-__device__ __forceinline__ uint32_t pack4(float a, float b, float c, float d, float qs) {
-    constexpr float LIM = FMT == FP8_E5M2 ? 57344.f : 448.f;
-    a = fminf(fmaxf(a * qs, -LIM), LIM); b = fminf(fmaxf(b * qs, -LIM), LIM);
-    c = fminf(fmaxf(c * qs, -LIM), LIM); d = fminf(fmaxf(d * qs, -LIM), LIM);
-    int w;
-    if constexpr (FMT == FP8_E5M2) { w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true); }
-    else { w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true); }
-    return (uint32_t)w;
-}
 template <int FMT>
 __device__ __forceinline__ u32x4 pack16(const float (&v)[16], float qs) {
-    return (u32x4){pack4<FMT>(v[0], v[1], v[2], v[3], qs), pack4<FMT>(v[4], v[5], v[6], v[7], qs),
-                   pack4<FMT>(v[8], v[9], v[10], v[11], qs), pack4<FMT>(v[12], v[13], v[14], v[15], qs)};
+    return (u32x4){fp8_pack4<FMT>(v[0], v[1], v[2], v[3], qs), fp8_pack4<FMT>(v[4], v[5], v[6], v[7], qs),
+                   fp8_pack4<FMT>(v[8], v[9], v[10], v[11], qs), fp8_pack4<FMT>(v[12], v[13], v[14], v[15], qs)};
 }
 __device__ __forceinline__ void amax_commit(Fp8Slot* slot, float amax) {
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&slot->amax_bits, __float_as_uint(amax));
 }
 
-// the block's bf16 output tile (LDS, [BM][BNT]) -> fp8 copies in global memory
-template <int BM, int BNT, int NT, int FMT>
-__device__ __forceinline__ void quant_tile(const __bf16* tile, const Epi& e, int batch, int row_blk, int col_blk, int M, int N) {
-    const float qs = e.qo->scale;
-    float amax = 0.f;
+// the two fp8 images the shared epilogue (Q8 mode) left in LDS -> global memory, 16 bytes per lane
+template <int BM, int BNT, int NT>
+__device__ __forceinline__ void copy_tile(const unsigned char* tr, const Epi& e, int batch, int row_blk, int col_blk, int M, int N) {
+    constexpr int PR = BNT + 16, PT = BM + 16;
+    const unsigned char* tt = tr + BM * PR;
     if (e.q8) {
         unsigned char* q8 = (unsigned char*)e.q8 + (long)batch * e.q8_bs;
         constexpr int CPR = BNT / 16;
         for (int c = threadIdx.x; c < BM * CPR; c += NT) {
             const int r = c / CPR, cc = (c - r * CPR) * 16;
-            if (row_blk + r < M && col_blk + cc < N) {
-                const bf16x8 lo = *(const bf16x8*)(tile + r * BNT + cc), hi = *(const bf16x8*)(tile + r * BNT + cc + 8);
-                float v[16];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { v[i] = (float)lo[i]; v[8 + i] = (float)hi[i]; }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
-                *(u32x4*)(q8 + (long)(row_blk + r) * e.ldq8 + col_blk + cc) = pack16<FMT>(v, qs);
-            }
+            if (row_blk + r < M && col_blk + cc < N)
+                *(u32x4*)(q8 + (long)(row_blk + r) * e.ldq8 + col_blk + cc) = *(const u32x4*)(tr + r * PR + cc);
         }
     }
     if (e.q8t) {
-        // 16 rows of one column per thread; neighbouring lanes take neighbouring columns (conflict-free LDS reads).
-        // Rows >= M inside a started 16-row group are stored as zeros, later groups keep the zeros of mrgan_create:
-        // the weight-gradient product reduces over all S rows of a segment.
+        // 16 lanes cover the BM rows of one column: BM contiguous bytes of the transposed row.  Row groups that start at or
+        // beyond M keep the zeros of mrgan_create (the weight-gradient product reduces over all S rows of a segment).
         unsigned char* q8t = (unsigned char*)e.q8t + (long)batch * e.q8t_bs;
-        for (int c = threadIdx.x; c < BNT * (BM / 16); c += NT) {
-            const int col = c % BNT, r0 = (c / BNT) * 16;
-            if (row_blk + r0 < M && col_blk + col < N) {
-                float v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = (row_blk + r0 + i < M) ? (float)tile[(r0 + i) * BNT + col] : 0.f;
-                if (!e.q8) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
-                }
-                *(u32x4*)(q8t + (long)(col_blk + col) * e.ldq8t + row_blk + r0) = pack16<FMT>(v, qs);
-            }
+        constexpr int RG = BM / 16;
+        for (int c = threadIdx.x; c < BNT * RG; c += NT) {
+            const int col = c / RG, r0 = (c - col * RG) * 16;
+            if (row_blk + r0 < M && col_blk + col < N)
+                *(u32x4*)(q8t + (long)(col_blk + col) * e.ldq8t + row_blk + r0) = *(const u32x4*)(tt + col * PT + r0);
         }
     }
-    amax_commit(e.qo, amax);
 }
 
 // operand formats per product: cbsz (A) / blgp (B) of the scaled MFMA, 0 = e4m3, 1 = e5m2
 template <int EPI> struct Fp8Fmt { static constexpr int A = EPI == EPI_DX ? 1 : 0, B = EPI == EPI_SLAB ? 1 : 0; };
 
-template <int EPI, int BM, int BNT, int WM, int WN, int VAR>
+// OUT8: the output leaves as fp8 copies (e.q8 / e.q8t) packed from the accumulators; otherwise as the bf16 tile (e.out)
+template <int EPI, int BM, int BNT, int WM, int WN, int VAR, bool OUT8>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int MR = BM / WM / 32, NR = BNT / WN / 32;
@@ -235,12 +209,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
         if constexpr (EPI == EPI_SLAB) {
             epilogue<__bf16, EPI_SLAB, MR, NR, WM, false, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BNT);
         } else {
-            // shared epilogue (bias / activation / mask / noise / column sums): bf16 tile assembled in LDS, optional bf16 store
-            epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
-                                                         (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf, nullptr);
-            if (g.e.q8 || g.e.q8t) {
-                if (g.e.q_fmt == FP8_E5M2) quant_tile<BM, BNT, 64 * NW, FP8_E5M2>((const __bf16*)lds, g.e, batch, row_blk, col_blk, g.M, g.N);
-                else quant_tile<BM, BNT, 64 * NW, FP8_E4M3>((const __bf16*)lds, g.e, batch, row_blk, col_blk, g.M, g.N);
+            // shared epilogue (bias / activation / mask / noise / column sums).  An fp8 output (e4m3 after a forward product,
+            // e5m2 after a dX product) is packed straight from the accumulators into two LDS byte images and copied out;
+            // a bf16 output (feature layer, d loss / d fake x) takes the bf16 tile path of the bf16 kernels.
+            if constexpr (OUT8) {
+                constexpr int QFMT = EPI == EPI_FWD ? FP8_E4M3 : FP8_E5M2;
+                constexpr int Q_BYTES = BM * (BNT + 16) + BNT * (BM + 16);
+                epilogue<__bf16, EPI, MR, NR, WM, true, VAR, QFMT>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
+                                                                   (float*)(lds + Q_BYTES), BNT, (__bf16*)lds, &pf, nullptr);
+                __syncthreads();
+                copy_tile<BM, BNT, 64 * NW>((const unsigned char*)lds, g.e, batch, row_blk, col_blk, g.M, g.N);
+            } else {
+                epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
+                                                             (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf, nullptr);
             }
         }
         __syncthreads();
@@ -334,14 +315,15 @@ __global__ void fp8_init_slots_kernel(Fp8Slot* slots, int n, const float* target
     slots[i] = Fp8Slot{0u, 1.0f, 1.0f, targets[i]};
 }
 
-template <int EPI, int BM, int BNT, int WM, int WN, int VAR>
+template <int EPI, int BM, int BNT, int WM, int WN, int VAR, bool OUT8>
 int launch_fp8_cfg(const GemmArgs& g, hipStream_t s) {
-    constexpr int STAGE = BM * 128 + BNT * 128, OUT = BM * BNT * 2 + 4 * WM * BNT * 4;
+    constexpr int STAGE = BM * 128 + BNT * 128, SCRATCH = 4 * WM * BNT * 4;
+    constexpr int OUT = (OUT8 ? BM * (BNT + 16) + BNT * (BM + 16) : BM * BNT * 2) + SCRATCH;
     constexpr int LDS = 2 * STAGE > OUT ? 2 * STAGE : OUT;
     static_assert(LDS <= 160 * 1024, "the ring exceeds the LDS of a CU");
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch;
     dim3 grid(std::min(tiles, 256 * std::max(1, (160 * 1024) / LDS)));
-    auto kern = gemm_fp8_kc_kernel<EPI, BM, BNT, WM, WN, VAR>;
+    auto kern = gemm_fp8_kc_kernel<EPI, BM, BNT, WM, WN, VAR, OUT8>;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
@@ -351,9 +333,9 @@ int launch_fp8_cfg(const GemmArgs& g, hipStream_t s) {
     return 0;
 }
 
-template <int EPI, int VAR>
+template <int EPI, int VAR, bool OUT8>
 int launch_fp8_var(const GemmArgs& g, hipStream_t s, bool big) {
-    return big ? launch_fp8_cfg<EPI, 256, 256, 2, 4, VAR>(g, s) : launch_fp8_cfg<EPI, 128, 128, 2, 2, VAR>(g, s);
+    return big ? launch_fp8_cfg<EPI, 256, 256, 2, 4, VAR, OUT8>(g, s) : launch_fp8_cfg<EPI, 128, 128, 2, 2, VAR, OUT8>(g, s);
 }
 
 }  // namespace
@@ -403,23 +385,28 @@ int launch_gemm_fp8(int epi, const GemmArgs& g, hipStream_t s, const char** knam
     const bool noise = e.sigma > 0.f, mask = e.mask != nullptr;
     int r = -3;
     const char* nm = "?";
+    const bool out8 = e.q8 || e.q8t;
+    if (epi != EPI_SLAB && out8 == (e.out != nullptr)) return -3;      // exactly one output form per forward / dX launch
     if (epi == EPI_FWD) {
         nm = big ? "gemm_fp8_kc_kernel<0, 256, 256>" : "gemm_fp8_kc_kernel<0, 128, 128>";
         if (e.cs_mode != CS_NONE && e.cs_mode != CS_SUM) return -3;
-        if (e.act == ACT_RELU && noise && mask) r = launch_fp8_var<EPI_FWD, ACT_RELU | VAR_NOISE | VAR_MASK>(g, s, big);
-        else if (e.act == ACT_RELU && !noise && mask) r = launch_fp8_var<EPI_FWD, ACT_RELU | VAR_MASK>(g, s, big);
-        else if (e.act == ACT_RELU && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_RELU>(g, s, big);
-        else if (e.act == ACT_LINEAR && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_LINEAR>(g, s, big);
-        else if (e.act == ACT_SOFTPLUS && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_SOFTPLUS>(g, s, big);
+        if (out8) {
+            if (e.act == ACT_RELU && noise && mask) r = launch_fp8_var<EPI_FWD, ACT_RELU | VAR_NOISE | VAR_MASK, true>(g, s, big);
+        } else {
+            if (e.act == ACT_RELU && !noise && mask) r = launch_fp8_var<EPI_FWD, ACT_RELU | VAR_MASK, false>(g, s, big);
+            else if (e.act == ACT_RELU && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_RELU, false>(g, s, big);
+            else if (e.act == ACT_LINEAR && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_LINEAR, false>(g, s, big);
+            else if (e.act == ACT_SOFTPLUS && !noise && !mask) r = launch_fp8_var<EPI_FWD, ACT_SOFTPLUS, false>(g, s, big);
+        }
     } else if (epi == EPI_DX) {
         nm = big ? "gemm_fp8_kc_kernel<1, 256, 256>" : "gemm_fp8_kc_kernel<1, 128, 128>";
         if (e.cs_mode != CS_NONE && e.cs_mode != CS_SUM) return -3;
-        if (e.act == ACT_RELU && mask) r = launch_fp8_var<EPI_DX, ACT_RELU>(g, s, big);
-        else if (e.act == ACT_LINEAR) r = launch_fp8_var<EPI_DX, ACT_LINEAR>(g, s, big);
+        if (out8) { if (e.act == ACT_RELU && mask) r = launch_fp8_var<EPI_DX, ACT_RELU, true>(g, s, big); }
+        else if (e.act == ACT_LINEAR) r = launch_fp8_var<EPI_DX, ACT_LINEAR, false>(g, s, big);
     } else if (epi == EPI_SLAB) {
         nm = big ? "gemm_fp8_kc_kernel<2, 256, 256>" : "gemm_fp8_kc_kernel<2, 128, 128>";
         if (!e.slab) return -3;
-        r = launch_fp8_var<EPI_SLAB, ACT_LINEAR>(g, s, big);
+        r = launch_fp8_var<EPI_SLAB, ACT_LINEAR, false>(g, s, big);
     }
     if (kname) *kname = nm;
     if (r) return r;

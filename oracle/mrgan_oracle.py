@@ -343,7 +343,8 @@ class MRGANOracle(object):
 #                     which pins the mirror's structure to the autograd-checked restatement.
 #   quantize='fp8'  : the bf16 dataflow, with the operands of the discriminator's dense products (forward, dX, dW)
 #                     additionally rounded to OCP fp8 (e4m3 activations / weights, e5m2 gradients) under delayed per-tensor
-#                     power-of-two scales, as gemm_fp8.hip stores them: fp8(bf16(v) * scale).
+#                     power-of-two scales, as gemm_fp8.hip stores them: fp8(v * scale) from the accumulator of the producing
+#                     product, fp8(bf16(v) * scale) where a bf16 tensor is converted (xin_0, the head's dpre, weights).
 #   quantize='bf16' : every tensor the engine STORES as bf16 is rounded (RNE) where the engine rounds it: GEMM weight
 #                     copies, z, the noisy layer inputs, h1 / BN(h1) / h2, every dpre / dX activation.  Batch
 #                     statistics, bias gradients and column sums come from the unrounded fp32 values, as on the device;
@@ -384,7 +385,9 @@ class Fp8Slots(object):
         self.scale, self.amax, self.fmt = {}, {}, {}
 
     def quant(self, v, key, fmt):
-        """v: bf16-valued array -> dequantised fp8(v * scale) / scale; records max |v| for the next pass's scale"""
+        """v -> dequantised fp8(v * scale) / scale; records max |v| (as fp32) for the next pass's scale.  v is bf16-valued where
+        the engine quantises a stored bf16 tensor (quant8_kernel: xin_0, the loss head's dpre, weights) and the unrounded
+        result where a product's epilogue packs its accumulator"""
         self.fmt[key] = fmt
         sc = self.scale.get(key, np.float32(1.0))
         self.amax[key] = max(self.amax.get(key, np.float32(0.0)), np.float32(np.abs(v).max() if v.size else 0.0))
@@ -435,7 +438,8 @@ class MRGANMirror(object):
             a = relu(xin[l] @ self.w8[l] + self.d[2 * l + 1])
             masks.append(a > 0)
             if l < nl - 2:
-                xin.append(sl.quant(q(a + np.asarray(self.sigmas[l + 1], a.dtype) * noise[l + 1]), ('x', kind, l + 1), 'e4m3'))
+                # packed straight from the fp32 accumulator by the forward epilogue: one rounding (no bf16 in between)
+                xin.append(sl.quant(a + np.asarray(self.sigmas[l + 1], a.dtype) * noise[l + 1], ('x', kind, l + 1), 'e4m3'))
         return dict(xin=xin, masks=masks, feat=a, feat_q=q(a))
 
     def _disc_bwd8(self, c, dpre_top, kind, to_input=False):
@@ -447,7 +451,7 @@ class MRGANMirror(object):
         for l in range(nl - 2, 0, -1):
             v = (dpre[l] @ self.w8[l].T) * c['masks'][l - 1]
             db[l - 1] = v.sum(axis=0)
-            dpre[l - 1] = sl.quant(q(v), ('g', kind, l - 1), 'e5m2')
+            dpre[l - 1] = sl.quant(v, ('g', kind, l - 1), 'e5m2')          # from the dX epilogue's accumulator, one rounding
         dx = dpre[0] @ self.w8[0].T if to_input else None
         return dpre, db, dx
 
