@@ -379,7 +379,9 @@ int launch_gemm_fp8(int epi, const GemmArgs& g, hipStream_t s, const char** knam
     if ((e.qa == nullptr) != (e.qb == nullptr)) return -3;
     // 256x256 blocks (8 waves of 128x64) once they fill the chip; e.tune_kc_cfg 1 / 3 force the small / large tile
     const int t256 = ceil_div(g.M, 256) * ceil_div(g.N, 256) * g.nbatch;
-    bool big = g.K >= 1024 && t256 >= 192 && (g.N % 256) == 0;
+    // (measured at configs[4]: the K = 512 first layer runs 0.18 vs 0.31 ms per launch on the large tile -- its epilogue writes
+    // three outputs per element and dominates, and the large tile halves the per-element epilogue overhead of the waves)
+    bool big = g.K >= 512 && t256 >= 192 && (g.N % 256) == 0;
     if (e.tune_kc_cfg == 1) big = false;
     if (e.tune_kc_cfg == 3 && (g.N % 256) == 0) big = true;
     const bool noise = e.sigma > 0.f, mask = e.mask != nullptr;
