@@ -65,6 +65,11 @@ struct HeadArgs {
     int off_db, off_dbf;                       //   [off_db .. +KMAX) = db6, [off_dbf .. +feat) = bias grad of the feature layer
     float* loss_part;                          // [blk][4] : sum loss_lab, sum loss_unl terms, sum err, 0
     int* err_count;                            // HEAD_EVAL: integer count of argmax != label
+    // fp8 mode: dpre leaves as e5m2 copies scaled by q8_slot->scale (row-major [seg][rows][ldq8] and transposed [feat][ldq8t] with
+    // segment s at row offset s * q8t_bs), max |dpre| -> q8_slot; dpre itself may then be null
+    unsigned char* q8; long q8_bs; int ldq8;
+    unsigned char* q8t; long q8t_bs; int ldq8t;
+    Fp8Slot* q8_slot;
 };
 int launch_head(int bf16, const HeadArgs& a, hipStream_t s);
 // dst[g][i] = sum over partial rows p = g, g+ngroups, ... of src[p][i]  (i < n, rows `stride` apart)
@@ -78,6 +83,7 @@ struct FmArgs {
     const uint16_t* mask; int ldm;                        // lane-native relu mask (gemm.h) of the fake rows' feature layer
     void* dpre; int ldd; int rows;
     float* loss_out; float* accum;                        // step scalar + epoch accumulator (block 0 only)
+    unsigned char* q8; int ldq8; Fp8Slot* q8_slot;        // fp8 mode: e5m2 copy of dpre (row-major), scaled by the slot; dpre may be null
 };
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s);
 
@@ -90,6 +96,7 @@ struct AdamTile {
     const float* g; int nslab; long slab_stride;       // gradient = sum of nslab slabs
     float* flat;                                       // flat gradient buffer (tile origin)
     __bf16* w16; __bf16* wt16;                         // bf16 copies [K][N] and [N][K] (null for fp32 / 1-D)
+    unsigned char* w8; unsigned char* w8t; Fp8Slot* w8_slot;      // fp8 mode: e4m3 copies of the bf16 values (same tile origins)
     int ld, ldt;                                       // row pitch of p/m/v/g/w16 ; of wt16
     int rows, cols;                                    // tile extent (<= 64 x 64)
 };

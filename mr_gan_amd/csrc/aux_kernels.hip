@@ -376,7 +376,13 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
         for (int rr = 0; rr < HR; ++rr) s += dl_lds[rr * KMAX + t];
         part_row[a.off_db + t] = s;
     }
-    T* dpre = (T*)a.dpre + (long)seg * a.dpre_bs;
+    T* dpre = a.dpre ? (T*)a.dpre + (long)seg * a.dpre_bs : nullptr;
+    // fp8 mode: the e5m2 copies of dpre that the dX / dW products read (one column's HR rows = HR contiguous bytes of the
+    // transposed copy); packed from the fp32 value
+    const float q8s = a.q8_slot ? a.q8_slot->scale : 1.f;
+    float q8_amax = 0.f;
+    unsigned char* q8 = a.q8 ? a.q8 + (long)seg * a.q8_bs : nullptr;
+    unsigned char* q8t = a.q8t ? a.q8t + (long)seg * a.q8t_bs : nullptr;
     // the last chunk is still in LDS: walk the chunks backwards and reload only the others
     for (int ch = nch - 1; ch >= 0; --ch) {
         const int c0 = ch * CH;
@@ -386,6 +392,9 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
 #pragma unroll
             for (int c = 0; c < KMAX; ++c) { wj[c] = w_lds[j * KMAX + c]; dw[c] = 0.f; }
             float dbf = 0.f;
+            uint32_t qw[HR / 4];
+            float q4[4];
+#pragma unroll
             for (int rr = 0; rr < HR; ++rr) {
                 const float fv = f_lds[rr * LDF + j];
                 const f32x4 d0 = *(const f32x4*)(dl_lds + rr * KMAX), d1 = *(const f32x4*)(dl_lds + rr * KMAX + 4);
@@ -396,14 +405,38 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
                     dw[c] = fmaf(fv, d0[c], dw[c]); dw[4 + c] = fmaf(fv, d1[c], dw[4 + c]);
                 }
                 const float dp = (fv > 0.f) ? dfe : 0.f;
-                if (row_blk + rr < a.rows) dpre[(long)(row_blk + rr) * a.ldd + c0 + j] = Elem<T>::from_f32(dp);
+                if (dpre && row_blk + rr < a.rows) dpre[(long)(row_blk + rr) * a.ldd + c0 + j] = Elem<T>::from_f32(dp);
                 dbf += dp;
+                if (a.q8_slot) {                  // (rows >= a.rows have dl == 0, hence dp == 0: zero bytes)
+                    q8_amax = fmaxf(q8_amax, fabsf(dp));
+                    q4[rr & 3] = dp;
+                    if ((rr & 3) == 3) qw[rr >> 2] = fp8_pack4<FP8_E5M2>(q4[0], q4[1], q4[2], q4[3], q8s);
+                }
+            }
+            if (a.q8_slot) {
+                if (q8t) {
+                    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#pragma unroll
+                    for (int k = 0; k < HR / 16; ++k)
+                        *(u32x4_t*)(q8t + (long)(c0 + j) * a.ldq8t + row_blk + 16 * k) = (u32x4_t){qw[4 * k], qw[4 * k + 1], qw[4 * k + 2], qw[4 * k + 3]};
+                }
+                if (q8) {
+                    // row-major copy: the four columns of a lane quad trade bytes, then each lane stores one dword per four rows
+                    // (CH and the loop stride are multiples of 4, so a quad is always inside the loop together)
+                    const int kq = t & 3;
+#pragma unroll
+                    for (int k = 0; k < HR / 4; ++k) {
+                        const uint32_t w = quad_byte_transpose(qw[k]);
+                        if (row_blk + 4 * k + kq < a.rows) *(uint32_t*)(q8 + (long)(row_blk + 4 * k + kq) * a.ldq8 + c0 + j - kq) = w;
+                    }
+                }
             }
             *(f32x4*)(part_row + (long)(c0 + j) * KMAX) = (f32x4){dw[0], dw[1], dw[2], dw[3]};
             *(f32x4*)(part_row + (long)(c0 + j) * KMAX + 4) = (f32x4){dw[4], dw[5], dw[6], dw[7]};
             part_row[a.off_dbf + c0 + j] = dbf;
         }
     }
+    if (a.q8_slot) fp8_amax_commit(a.q8_slot, q8_amax);
 }
 
 // dst[g][i] = sum of src[p][i] over the partial rows p of group g (p = g, g + ngroups, ...)
@@ -470,6 +503,8 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
     const int cg = t & 7, rl = t >> 3, c0 = col0 + cg * 8;
     if (c0 >= a.feat) return;
     T* dpre = (T*)a.dpre;
+    const float q8s = a.q8_slot ? a.q8_slot->scale : 1.f;
+    float q8_amax = 0.f;
     const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
     for (int r = blockIdx.y * RB + rl; r < r1; r += 32) {
         // lane-native mask layout (gemm.h): per (32-row block, column) two u16 words, one per lane half
@@ -478,8 +513,15 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (((mp[i] >> (16 * half)) >> bit) & 1u) ? gj_lds[cg * 8 + i] : 0.f;
-        store8<T>(dpre + (long)r * a.ldd + c0, v);
+        if (dpre) store8<T>(dpre + (long)r * a.ldd + c0, v);
+        if (a.q8_slot) {                          // fp8 mode: the e5m2 copy the dX product reads
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q8_amax = fmaxf(q8_amax, fabsf(v[i]));
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+            *(u32x2_t*)(a.q8 + (long)r * a.ldq8 + c0) = (u32x2_t){fp8_pack4<FP8_E5M2>(v[0], v[1], v[2], v[3], q8s), fp8_pack4<FP8_E5M2>(v[4], v[5], v[6], v[7], q8s)};
+        }
     }
+    if (a.q8_slot) fp8_amax_commit(a.q8_slot, q8_amax);
 }
 
 // two sets of per-row-tile partial sums -> two rows of `out` (out[0..n) and out[n..2n)); blockIdx.y picks the set
@@ -520,6 +562,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     const int qpr = tile.cols >> 2;                       // four-element groups per row
     const int nq = tile.rows * qpr;
     const bool small = nq <= 64 && !tile.wt16;            // slab-parallel mode
+    const float w8_scale = tile.w8_slot ? tile.w8_slot->scale : 1.f;
+    float w8_amax = 0.f;
     const int QL = nq <= 16 ? 16 : 64;                    // element-group slots; the other threads are slab lanes
     const int lanes = small ? 256 / QL : 1;
 #pragma unroll 1
@@ -555,6 +599,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
                 if (tile.w16) {
                     bf16x4 w = {(__bf16)pn[0], (__bf16)pn[1], (__bf16)pn[2], (__bf16)pn[3]};
                     *(bf16x4*)(tile.w16 + off) = w;
+                    if (tile.w8_slot) {           // fp8 mode: e4m3 copy of the bf16 values (what quant8_kernel would produce from w16)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { pn[i] = (float)w[i]; w8_amax = fmaxf(w8_amax, fabsf(pn[i])); }
+                        *(uint32_t*)(tile.w8 + off) = fp8_pack4<FP8_E4M3>(pn[0], pn[1], pn[2], pn[3], w8_scale);
+                    }
                 }
             }
         }
@@ -572,8 +621,18 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
             for (int i = 0; i < 8; ++i) { lo[i] = (__bf16)tl[cc * 65 + rr0 + i]; hi[i] = (__bf16)tl[cc * 65 + rr0 + 8 + i]; }
             *(bf16x8*)(tile.wt16 + (long)cc * tile.ldt + rr0) = lo;
             *(bf16x8*)(tile.wt16 + (long)cc * tile.ldt + rr0 + 8) = hi;
+            if (tile.w8_slot) {
+                typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+                float f[16];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { f[i] = (float)lo[i]; f[8 + i] = (float)hi[i]; }
+                *(u32x4_t*)(tile.w8t + (long)cc * tile.ldt + rr0) =
+                    (u32x4_t){fp8_pack4<FP8_E4M3>(f[0], f[1], f[2], f[3], w8_scale), fp8_pack4<FP8_E4M3>(f[4], f[5], f[6], f[7], w8_scale),
+                              fp8_pack4<FP8_E4M3>(f[8], f[9], f[10], f[11], w8_scale), fp8_pack4<FP8_E4M3>(f[12], f[13], f[14], f[15], w8_scale)};
+            }
         }
     }
+    if (tile.w8_slot && a.mode != ADAM_REDUCE_ONLY) fp8_amax_commit(tile.w8_slot, w8_amax);
     }
     // ---- the extra last block: the next sub-step's DevState, and this sub-step's loss partials ----
     if (blockIdx.x == a.ntiles && t == 0 && a.next && a.mode != ADAM_REDUCE_ONLY) {

@@ -148,6 +148,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
+// one fp8 tensor's scaling state.  Delayed scaling: a pass stores with `scale` (from the amax of the previous pass) and
+// records its own max |v| (before scaling); fp8_update_scales_kernel (gemm_fp8.hip) turns that into the next pass's scale.
+struct Fp8Slot { uint32_t amax_bits; float scale, inv_scale; float target; };
 // ---- fp8 (OCP e4m3 / e5m2) packing: four floats -> four bytes of v * qs, round to nearest even, saturating ----
 enum { FP8_E4M3 = 0, FP8_E5M2 = 1 };
 template <int FMT>
@@ -159,6 +162,28 @@ __device__ __forceinline__ uint32_t fp8_pack4(float a, float b, float c, float d
     if constexpr (FMT == FP8_E5M2) { w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true); }
     else { w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true); }
     return (uint32_t)w;
+}
+// 4 x 4 byte transpose inside each lane quad: lane k of the quad gets byte k of the four lanes' words (DPP broadcasts + v_perm)
+__device__ __forceinline__ uint32_t quad_byte_transpose(uint32_t w) {
+    const uint32_t kq = threadIdx.x & 3;
+    const uint32_t q0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x00, 0xF, 0xF, true);
+    const uint32_t q1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x55, 0xF, 0xF, true);
+    const uint32_t q2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xAA, 0xF, 0xF, true);
+    const uint32_t q3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xFF, 0xF, 0xF, true);
+    const uint32_t sel = kq * 0x01010101u + 0x04000400u;                 // bytes (k, 4 + k, k, 4 + k)
+    const uint32_t lo = __builtin_amdgcn_perm(q1, q0, sel), hi = __builtin_amdgcn_perm(q3, q2, sel);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+// wave-wide max of a non-negative value -> the slot's amax (float bits compare as integers)
+__device__ __forceinline__ void fp8_amax_commit(Fp8Slot* slot, float amax) {
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    // thousands of waves target one address, and same-address atomics serialise in L2 (measured: +0.3 ms per launch at
+    // 10 k waves): a wave whose maximum is not above the value it can already see skips the atomic (a stale read only costs
+    // an extra atomic)
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) {
+        const uint32_t bits = __float_as_uint(amax);
+        if (bits > *(volatile uint32_t*)&slot->amax_bits) atomicMax(&slot->amax_bits, bits);
+    }
 }
 
 }  // namespace mrgan

@@ -380,6 +380,9 @@ int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n,
                 a.flat = t.flat + off;
                 a.w16 = t.w16 ? t.w16 + off : nullptr;
                 a.wt16 = t.wt16 ? t.wt16 + (long)c0 * t.prow + r0 : nullptr;
+                a.w8 = a.w8t = nullptr; a.w8_slot = nullptr;
+                for (int l = 0; l < 5 && h->fp8; ++l)
+                    if (&t == h->d[l].W) { a.w8 = h->w8[l] + off; a.w8t = h->w8t[l] + (long)c0 * t.prow + r0; a.w8_slot = h->slots + slot_w(l); }
                 a.ld = t.pcol; a.ldt = t.prow;
                 a.rows = std::min(64, t.prow - r0); a.cols = std::min(64, t.pcol - c0);
                 v.push_back(a);
@@ -584,11 +587,6 @@ int fp8_quant_x0(mrgan_handle* h, int x0_slot, int nb, bool want_t, hipStream_t 
     const int S = h->S, Dp = h->Dp;
     return fp8_quant(h, rowptr(h, h->xin[0], (long)x0_slot * S, Dp), (long)S * Dp, Dp, h->B, Dp, (int)round_up(h->B, 64), nb, h->x8[0],
                      (long)S * Dp, Dp, want_t ? h->x8t[0] : nullptr, S, 3 * S, slot_x(h->fp8_kind, 0), FP8_E4M3, s);
-}
-int fp8_quant_top_grad(mrgan_handle* h, int nb, bool want_t, hipStream_t s) {
-    const int S = h->S, Fp = h->Fp;
-    return fp8_quant(h, h->dpre[4], (long)S * Fp, Fp, h->B, Fp, (int)round_up(h->B, 64), nb, h->g8[4], (long)S * Fp, Fp,
-                     want_t ? h->g8t[4] : nullptr, S, 3 * S, slot_g(h->fp8_kind, 4), FP8_E5M2, s);
 }
 int fp8_refresh_weights(mrgan_handle* h, hipStream_t s) {
     for (int l = 0; l < 5; ++l) {
@@ -895,6 +893,12 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         hd.dpre = h->dpre[4]; hd.dpre_bs = (long)h->S * h->Fp; hd.ldd = h->Fp;
         hd.part = h->head_part; hd.part_stride = h->head_stride; hd.off_db = h->Fp * KMAX; hd.off_dbf = h->Fp * KMAX + KMAX;
         hd.loss_part = h->loss_part;
+        if (h->fp8) {                 // the head writes the e5m2 copies of dpre itself (no bf16 dpre, no quantiser pass)
+            hd.dpre = nullptr;
+            hd.q8 = h->g8[4]; hd.q8_bs = (long)h->S * h->Fp; hd.ldq8 = h->Fp;
+            hd.q8t = h->g8t[4]; hd.q8t_bs = h->S; hd.ldq8t = 3 * h->S;
+            hd.q8_slot = h->slots + slot_g(0, 4);
+        }
         if (h->use_chain) {
             // D3 D4 D5 forward -> loss head -> dX through D5 D4 D3, one launch: the rows of a block never leave its CU
             ChainArgs c;
@@ -916,7 +920,6 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
             PROF("head_kernel", launch_head(h->bf16, hd, s));
         }
         if (h->fp8) {
-            CHK(fp8_quant_top_grad(h, 3, true, s));
             for (int l = 4; l >= 1; --l) CHK(fp8_dx(h, l, 3, true, true, s));
             for (int l = 0; l < 5; ++l) CHK(fp8_dw(h, l, 3, s));
             PROF("reduce_partials_kernel", launch_reduce_partials(h->head_part, head_blocks(h), h->head_stride, h->head_stride, h->head_groups, h->head_red, s));
@@ -935,7 +938,7 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_D, ADAM_REDUCE_ONLY, true, s));
     } else if (phase == MRGAN_D_ADAM) {
         CHK(run_adam(h, MRGAN_NET_D, h->flat_grads ? ADAM_FROM_FLAT : ADAM_FUSED, true, s));
-        if (h->fp8) { CHK(fp8_refresh_weights(h, s)); CHK(fp8_update_scales(h, s)); }
+        if (h->fp8) CHK(fp8_update_scales(h, s));        // (the Adam kernel rewrote the fp8 weight copies and their amax)
         h->cur ^= 1;
     }
     return 0;
@@ -993,6 +996,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         f.ldcs = h->Fp; f.count = h->stat_count; f.grad_scale = h->fm_scale; f.feat = h->Fp; f.feat_valid = h->F;
         f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B;
         f.loss_out = h->step_out + 3; f.accum = h->accum + 3;
+        if (h->fp8) { f.dpre = nullptr; f.q8 = h->g8[4]; f.ldq8 = h->Fp; f.q8_slot = h->slots + slot_g(1, 4); }
         if (h->use_chain) {
             // feature-matching gradient -> dX through D5 D4 D3 on the generated rows, one launch
             ChainArgs c;
@@ -1009,7 +1013,6 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
             PROF("fm_kernel", launch_fm(h->bf16, f, s));
         }
         if (h->fp8) {
-            CHK(fp8_quant_top_grad(h, 1, false, s));
             for (int l = 4; l >= 0; --l) CHK(fp8_dx(h, l, 1, false, false, s));
         } else {
         for (int l = h->use_chain ? 1 : 4; l >= 1; --l)

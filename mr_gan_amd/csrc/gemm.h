@@ -23,9 +23,6 @@ enum { EPI_FWD = 0, EPI_DX = 1, EPI_SLAB = 2 };
 // (the fp32 parity kernels, where epilogue speed is irrelevant).
 enum { VAR_ACT_MASK = 3, VAR_NOISE = 4, VAR_MASK = 8, VAR_DYN = 64 };
 
-// one fp8 tensor's scaling state.  Delayed scaling: a pass stores with `scale` (from the amax of the previous pass) and
-// records its own max |v| (before scaling); fp8_update_scales_kernel turns that into the next pass's scale.
-struct Fp8Slot { uint32_t amax_bits; float scale, inv_scale; float target; };
 
 struct Epi {
     int act;                 // FWD: activation; DX: derivative applied (RELU mask / SOFTPLUS from h / LINEAR)
@@ -265,13 +262,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                         // row-major image: 4 x 4 byte transpose inside each lane quad (4 neighbouring columns) by DPP
                         // broadcasts + v_perm, then one dword per lane = row r4 + (lane & 3), columns of the quad
                         const int kq = lane & 3;
-                        const uint32_t q0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x00, 0xF, 0xF, true);
-                        const uint32_t q1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x55, 0xF, 0xF, true);
-                        const uint32_t q2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xAA, 0xF, 0xF, true);
-                        const uint32_t q3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xFF, 0xF, 0xF, true);
-                        const uint32_t sel = (uint32_t)kq * 0x01010101u + 0x04000400u;           // bytes (k, 4 + k, k, 4 + k)
-                        const uint32_t lo = __builtin_amdgcn_perm(q1, q0, sel), hi = __builtin_amdgcn_perm(q3, q2, sel);
-                        *(uint32_t*)(q8r + (rl + kq) * (bn + 16) + (cl - kq)) = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                        *(uint32_t*)(q8r + (rl + kq) * (bn + 16) + (cl - kq)) = quad_byte_transpose(w);
                     } else if constexpr (STAGED) {
                         // rows r4 .. r4+3 of one column: convert in pairs (one v_cvt_pk per two values), store the halves
                         T* tp = tile + (r4 - row_blk) * bn + (col - col_blk);
@@ -294,8 +285,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
         }
 
         if constexpr (Q8 >= 0) {
-            for (int o = 32; o > 0; o >>= 1) q8_amax = fmaxf(q8_amax, __shfl_xor(q8_amax, o, 64));
-            if (lane == 0 && q8_amax > 0.f) atomicMax(&e.qo->amax_bits, __float_as_uint(q8_amax));
+            fp8_amax_commit(e.qo, q8_amax);
         } else if constexpr (STAGED) {
             typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
             constexpr int EPV = 16 / (int)sizeof(T);               // elements per 16-byte chunk

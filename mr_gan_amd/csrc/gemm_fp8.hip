@@ -41,11 +41,6 @@ __device__ __forceinline__ u32x4 pack16(const float (&v)[16], float qs) {
     return (u32x4){fp8_pack4<FMT>(v[0], v[1], v[2], v[3], qs), fp8_pack4<FMT>(v[4], v[5], v[6], v[7], qs),
                    fp8_pack4<FMT>(v[8], v[9], v[10], v[11], qs), fp8_pack4<FMT>(v[12], v[13], v[14], v[15], qs)};
 }
-__device__ __forceinline__ void amax_commit(Fp8Slot* slot, float amax) {
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(&slot->amax_bits, __float_as_uint(amax));
-}
-
 // the two fp8 images the shared epilogue (Q8 mode) left in LDS -> global memory, 16 bytes per lane
 template <int BM, int BNT, int NT>
 __device__ __forceinline__ void copy_tile(const unsigned char* tr, const Epi& e, int batch, int row_blk, int col_blk, int M, int N) {
@@ -289,7 +284,7 @@ __global__ __launch_bounds__(256) void quant8_kernel(const Quant8Args a) {
             }
         }
     }
-    amax_commit(a.slot, amax);
+    fp8_amax_commit(a.slot, amax);
 }
 
 // delayed scaling: next scale = 2^floor(log2(target / amax)) from the exponent field of the fp32 quotient (bit-exact on

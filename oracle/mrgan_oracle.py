@@ -344,7 +344,8 @@ class MRGANOracle(object):
 #   quantize='fp8'  : the bf16 dataflow, with the operands of the discriminator's dense products (forward, dX, dW)
 #                     additionally rounded to OCP fp8 (e4m3 activations / weights, e5m2 gradients) under delayed per-tensor
 #                     power-of-two scales, as gemm_fp8.hip stores them: fp8(v * scale) from the accumulator of the producing
-#                     product, fp8(bf16(v) * scale) where a bf16 tensor is converted (xin_0, the head's dpre, weights).
+#                     product / loss head / feature-matching kernel, fp8(bf16(v) * scale) where a bf16 tensor is converted
+#                     (xin_0, weights).
 #   quantize='bf16' : every tensor the engine STORES as bf16 is rounded (RNE) where the engine rounds it: GEMM weight
 #                     copies, z, the noisy layer inputs, h1 / BN(h1) / h2, every dpre / dX activation.  Batch
 #                     statistics, bias gradients and column sums come from the unrounded fp32 values, as on the device;
@@ -386,8 +387,8 @@ class Fp8Slots(object):
 
     def quant(self, v, key, fmt):
         """v -> dequantised fp8(v * scale) / scale; records max |v| (as fp32) for the next pass's scale.  v is bf16-valued where
-        the engine quantises a stored bf16 tensor (quant8_kernel: xin_0, the loss head's dpre, weights) and the unrounded
-        result where a product's epilogue packs its accumulator"""
+        the engine quantises a stored bf16 tensor (xin_0, the bf16 weight copies) and the unrounded result where a product's
+        epilogue, the loss head or the feature-matching kernel packs its fp32 value"""
         self.fmt[key] = fmt
         sc = self.scale.get(key, np.float32(1.0))
         self.amax[key] = max(self.amax.get(key, np.float32(0.0)), np.float32(np.abs(v).max() if v.size else 0.0))
@@ -471,7 +472,7 @@ class MRGANMirror(object):
             grads[-1] += dl.sum(axis=0)
             dp = (dl @ W6.T) * (c['feat_q'] > 0)
             grads[2 * (nl - 2) + 1] += dp.sum(axis=0)
-            dpre, db, _ = self._disc_bwd8(c, q(dp), 0)
+            dpre, db, _ = self._disc_bwd8(c, dp, 0)            # the loss head packs e5m2 from the fp32 value
             for l in range(nl - 1):
                 grads[2 * l] += c['xin'][l].T @ dpre[l]
                 if l < nl - 2:
@@ -616,7 +617,7 @@ class MRGANMirror(object):
         loss = np.mean(diff * diff)
         gj = (2.0 / (J * B)) * diff
         if self.fp8:
-            _, _, v = self._disc_bwd8(cf, q(np.where(cf['masks'][-1], gj, 0.0)), 1, to_input=True)
+            _, _, v = self._disc_bwd8(cf, np.where(cf['masks'][-1], gj, 0.0), 1, to_input=True)     # fm_kernel: e5m2 from fp32
         else:
             dpre, _ = self._disc_bwd(cf, q(np.where(cf['masks'][-1], gj, 0.0)), False)
             v = dpre[0] @ q(self.d[0]).T                                          # d loss / d x_fake (noise is additive)
