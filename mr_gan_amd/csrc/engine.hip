@@ -68,10 +68,12 @@ struct Dense {
 struct ProfRec { int cat; hipEvent_t start, stop; double flops, bytes; };      // device-side begin / end of one kernel (MRGAN_LAUNCH)
 
 // fp8 scaling slots: kind 0 = D sub-step, 1 = G sub-step; X = activations (e4m3), G = gradients (e5m2), W = weights (e4m3)
-constexpr int FP8_NSLOT = 25, FP8_DRY_PASSES = 5;
+constexpr int FP8_NSLOT = 28, FP8_DRY_PASSES = 5;
 inline int slot_x(int kind, int l) { return kind * 10 + l; }
 inline int slot_g(int kind, int l) { return kind * 10 + 5 + l; }
 inline int slot_w(int l) { return 20 + l; }
+// the generator's 4096 x 4096-class layer G2 (hbn -> h2): input, output gradient, weight
+constexpr int SLOT_GX = 25, SLOT_GG = 26, SLOT_GW = 27;
 constexpr float FP8_TARGET_E4M3 = 224.0f, FP8_TARGET_E5M2 = 28672.0f;      // half the largest finite value: 2x headroom
 
 struct Arena {
@@ -126,6 +128,8 @@ struct mrgan_handle {
     // of its weights, and the scaling slots (index fp8_slot())
     bool fp8; int fp8_kind; int fp8_cal[2];
     unsigned char *x8[5], *x8t[5], *g8[5], *g8t[5], *w8[5], *w8t[5];
+    unsigned char *hbn8, *hbn8t, *dp2g8, *dp2g8t, *gw8, *gw8t;      // generator layer G2: BN(h1) [2][S][N1], dpre2 [S][N2], W2
+    int gen_seg;                                                  // segment the generator views point at (set_gen_view)
     Fp8Slot* slots; float* slot_targets; float* accum_save;
     bool chain_ok, use_chain;            // the 256-wide tail of the discriminator runs as row-block chain launches (gemm_chain.hip)
     int tune_kc_cfg, tune_bits, tune_pair_gen;      // mrgan_set_tuning
@@ -302,6 +306,12 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
             h->g8[l] = a.take<unsigned char>(3 * (size_t)S * L.Np); h->g8t[l] = a.take<unsigned char>(3 * (size_t)S * L.Np);
             h->w8[l] = a.take<unsigned char>((size_t)L.Kp * L.Np); h->w8t[l] = a.take<unsigned char>((size_t)L.Kp * L.Np);
         }
+        {
+            const Dense& L = h->g[1];
+            h->hbn8 = a.take<unsigned char>(2 * (size_t)S * L.Kp); h->hbn8t = a.take<unsigned char>(2 * (size_t)S * L.Kp);
+            h->dp2g8 = a.take<unsigned char>((size_t)S * L.Np); h->dp2g8t = a.take<unsigned char>((size_t)S * L.Np);
+            h->gw8 = a.take<unsigned char>((size_t)L.Kp * L.Np); h->gw8t = a.take<unsigned char>((size_t)L.Kp * L.Np);
+        }
         h->slots = a.take<Fp8Slot>(FP8_NSLOT); h->slot_targets = a.take<float>(FP8_NSLOT); h->accum_save = a.take<float>(4);
     }
     h->dxfake = act(S, h->Dp); h->dpre2g = act(S, h->g[1].Np); h->dhbn = act(S, N1p); h->dpre1g = act(S, N1p);
@@ -337,7 +347,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     }
     for (int l = 0; l < 3; ++l) {
         Dense& L = h->g[l];
-        L.splits = choose_splits(tiles_g, B);
+        L.splits = (h->fp8 && l == 1) ? 1 : choose_splits(tiles_g, B);       // fp8: G2's weight gradient is one fp8 product
         L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     // ---- fused-mode gradient sources ----------------------------------------------------------------
@@ -383,6 +393,7 @@ int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n,
                 a.w8 = a.w8t = nullptr; a.w8_slot = nullptr;
                 for (int l = 0; l < 5 && h->fp8; ++l)
                     if (&t == h->d[l].W) { a.w8 = h->w8[l] + off; a.w8t = h->w8t[l] + (long)c0 * t.prow + r0; a.w8_slot = h->slots + slot_w(l); }
+                if (h->fp8 && &t == h->g[1].W) { a.w8 = h->gw8 + off; a.w8t = h->gw8t + (long)c0 * t.prow + r0; a.w8_slot = h->slots + SLOT_GW; }
                 a.ld = t.pcol; a.ldt = t.prow;
                 a.rows = std::min(64, t.prow - r0); a.cols = std::min(64, t.pcol - c0);
                 v.push_back(a);
@@ -588,12 +599,63 @@ int fp8_quant_x0(mrgan_handle* h, int x0_slot, int nb, bool want_t, hipStream_t 
     return fp8_quant(h, rowptr(h, h->xin[0], (long)x0_slot * S, Dp), (long)S * Dp, Dp, h->B, Dp, (int)round_up(h->B, 64), nb, h->x8[0],
                      (long)S * Dp, Dp, want_t ? h->x8t[0] : nullptr, S, 3 * S, slot_x(h->fp8_kind, 0), FP8_E4M3, s);
 }
-int fp8_refresh_weights(mrgan_handle* h, hipStream_t s) {
+GemmArgs fp8_args(mrgan_handle* h, int M, int N, int K, int nb);
+int fp8_refresh_weights(mrgan_handle* h, int net, hipStream_t s) {
+    if (net == MRGAN_NET_G) {
+        const Dense& L = h->g[1];
+        return fp8_quant(h, L.W->w16, 0, L.Np, L.Kp, L.Np, L.Kp, 1, h->gw8, 0, L.Np, h->gw8t, 0, L.Kp, SLOT_GW, FP8_E4M3, s);
+    }
     for (int l = 0; l < 5; ++l) {
         const Dense& L = h->d[l];
         CHK(fp8_quant(h, L.W->w16, 0, L.Np, L.Kp, L.Np, L.Kp, 1, h->w8[l], 0, L.Np, h->w8t[l], 0, L.Kp, slot_w(l), FP8_E4M3, s));
     }
     return 0;
+}
+// generator layer G2 in fp8 (the one wide product of the generator): h2 = softplus(BN(h1) W2 + b2) over nb segments from the
+// current view; BN(h1) is quantised with its transpose (the weight gradient of the G sub-step reads it)
+int fp8_gen_g2_fwd(mrgan_handle* h, int nb, hipStream_t s) {
+    const Dense& L = h->g[1];
+    const int S = h->S;
+    unsigned char* x8 = h->hbn8 + (size_t)h->gen_seg * S * L.Kp;
+    CHK(fp8_quant(h, h->hbn, (long)S * L.Kp, L.Kp, h->B, L.Kp, (int)round_up(h->B, 64), nb, x8, (long)S * L.Kp, L.Kp,
+                  h->hbn8t + (size_t)h->gen_seg * S, S, 2 * S, SLOT_GX, FP8_E4M3, s));
+    GemmArgs g = fp8_args(h, h->B, L.Np, L.Kp, nb);
+    g.A = x8; g.a_bs = (long)S * L.Kp; g.a_si = L.Kp;
+    g.B = h->gw8t; g.b_sj = L.Kp;
+    Epi& e = g.e;
+    e.act = ACT_SOFTPLUS; e.n_valid = L.N; e.bias = L.b->p;
+    e.out = h->h2; e.out_bs = (long)S * L.Np; e.ldo = L.Np;
+    e.qa = h->slots + SLOT_GX; e.qb = h->slots + SLOT_GW;
+    return run_gemm_fp8(h, EPI_FWD, g, 2.0 * h->B * nb * L.K * L.N, s);
+}
+// backward through G2: dpre2 (bf16, from the G3 dX product) -> e5m2 (+ transpose); d(BN out) = dpre2 W2^T with the BatchNorm
+// backward sums; dW2 = BN(h1)^T dpre2
+int fp8_gen_g2_bwd(mrgan_handle* h, hipStream_t s) {
+    const Dense& L = h->g[1];
+    const int S = h->S;
+    CHK(fp8_quant(h, h->dpre2g, 0, L.Np, h->B, L.Np, (int)round_up(h->B, 64), 1, h->dp2g8, 0, L.Np, h->dp2g8t, 0, S, SLOT_GG, FP8_E5M2, s));
+    GemmArgs g = fp8_args(h, h->B, L.Kp, L.Np, 1);
+    g.A = h->dp2g8; g.a_si = L.Np;
+    g.B = h->gw8; g.b_sj = L.Np;
+    Epi& e = g.e;
+    e.act = ACT_LINEAR; e.n_valid = h->g[0].N;
+    e.out = h->dhbn; e.ldo = L.Kp;
+    e.h = h->h1; e.ldh = L.Kp;
+    e.cs_mode = CS_SUM_XHAT; e.cs1 = h->cs_dbeta; e.cs2 = h->cs_dgamma; e.ldcs = L.Kp;
+    e.bn_mu = h->bn_mu; e.bn_rstd = h->bn_rstd;
+    e.qa = h->slots + SLOT_GG; e.qb = h->slots + SLOT_GW;
+    return run_gemm_fp8(h, EPI_DX, g, 2.0 * h->B * L.K * L.N, s);
+}
+int fp8_gen_g2_dw(mrgan_handle* h, hipStream_t s) {
+    const Dense& L = h->g[1];
+    const int S = h->S;
+    GemmArgs g = fp8_args(h, L.Kp, L.Np, S, 1);
+    g.tiles_m = ceil_div(L.Kp, 128);
+    g.A = h->hbn8t + (size_t)h->gen_seg * S; g.a_si = 2 * S;
+    g.B = h->dp2g8t; g.b_sj = S;
+    g.e.qa = h->slots + SLOT_GX; g.e.qb = h->slots + SLOT_GG;
+    g.e.ldo = L.Np; g.e.slab = L.slabs; g.e.slab_stride = (long)L.Kp * L.Np;
+    return run_gemm_fp8(h, EPI_SLAB, g, 2.0 * h->B * L.K * L.N, s);
 }
 int fp8_update_scales(mrgan_handle* h, hipStream_t s) {
     PROF("fp8_update_scales_kernel", launch_fp8_update_scales(h->slots, FP8_NSLOT, s));
@@ -701,6 +763,7 @@ int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t 
 
 // which of the two generator-activation segments the following kernels work on
 void set_gen_view(mrgan_handle* h, int seg) {
+    h->gen_seg = seg;
     const int N1p = h->g[0].Np;
     h->zbuf = rowptr(h, h->zbuf_all, (long)seg * h->S, h->nzp);
     h->h1 = rowptr(h, h->h1_all, (long)seg * h->S, N1p);
@@ -736,7 +799,8 @@ int gen_fwd_tail(mrgan_handle* h, int nb, int fake_seg_slot, uint32_t fake_seg_i
     b.ldcs = n; b.count = h->stat_count; b.eps = h->cfg.bn_eps;
     b.gamma = h->gt[2].p; b.beta = h->gt[3].p; b.mu = h->bn_mu; b.rstd = h->bn_rstd;
     PROF("bn_apply_kernel", launch_bn_apply(h->bf16, b, s));
-    CHK(dense_fwd(h, h->g[1], h->hbn, h->B, nb, h->h2, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_NONE, nullptr, nullptr, true, s));
+    if (h->fp8) CHK(fp8_gen_g2_fwd(h, nb, s));
+    else CHK(dense_fwd(h, h->g[1], h->hbn, h->B, nb, h->h2, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_NONE, nullptr, nullptr, true, s));
     // generator output + GaussianNoise(sigma0) = the discriminator's noisy input rows of the fake segment.
     // Paired: segment 1 lands in the next xin[0] slot and is drawn as (segment id 0, iteration + 1), the G sub-step's fake rows.
     void* out = rowptr(h, h->xin[0], (long)fake_seg_slot * h->S, h->Dp);
@@ -1024,8 +1088,9 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         }
         CHK(dense_dx(h, h->g[2], h->dxfake, B, 1, h->dpre2g, ACT_SOFTPLUS, h->g[1].N, nullptr, 0, h->h2, CS_SUM, h->cs_db2g,
                      nullptr, s));
-        CHK(dense_dx(h, h->g[1], h->dpre2g, B, 1, h->dhbn, ACT_LINEAR, h->g[0].N, nullptr, 0, h->h1, CS_SUM_XHAT, h->cs_dbeta,
-                     h->cs_dgamma, s));
+        if (h->fp8) CHK(fp8_gen_g2_bwd(h, s));
+        else CHK(dense_dx(h, h->g[1], h->dpre2g, B, 1, h->dhbn, ACT_LINEAR, h->g[0].N, nullptr, 0, h->h1, CS_SUM_XHAT, h->cs_dbeta,
+                          h->cs_dgamma, s));
         if (h->sync_stats) {
             PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_dbeta, h->cs_dgamma, tm, N1p, N1p, h->r_bn_bwd, s));
         }
@@ -1039,8 +1104,9 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         b.db_part = h->db1g_part;
         PROF("bn_bwd_kernel", launch_bn_bwd(h->bf16, b, s));
         {
-            const DwJob jobs[3] = {{&h->g[2], h->h2, h->dxfake}, {&h->g[1], h->hbn, h->dpre2g}, {&h->g[0], h->zbuf, h->dpre1g}};
-            CHK(dense_dw_all(h, jobs, 3, B, 1, s));
+            const DwJob jobs[3] = {{&h->g[2], h->h2, h->dxfake}, {&h->g[0], h->zbuf, h->dpre1g}, {&h->g[1], h->hbn, h->dpre2g}};
+            if (h->fp8) { CHK(dense_dw_all(h, jobs, 2, B, 1, s)); CHK(fp8_gen_g2_dw(h, s)); }
+            else CHK(dense_dw_all(h, jobs, 3, B, 1, s));
         }
         if (h->flat_grads) CHK(run_adam(h, MRGAN_NET_G, ADAM_REDUCE_ONLY, false, s));
     } else if (phase == MRGAN_G_ADAM) {
@@ -1236,6 +1302,7 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
         for (int k = 0; k < 2; ++k)
             for (int l = 0; l < 5; ++l) { tg[slot_x(k, l)] = FP8_TARGET_E4M3; tg[slot_g(k, l)] = FP8_TARGET_E5M2; }
         for (int l = 0; l < 5; ++l) tg[slot_w(l)] = FP8_TARGET_E4M3;
+        tg[SLOT_GX] = FP8_TARGET_E4M3; tg[SLOT_GG] = FP8_TARGET_E5M2; tg[SLOT_GW] = FP8_TARGET_E4M3;
         CREATE_CHK(hipMemcpyAsync(h->slot_targets, tg, sizeof tg, hipMemcpyHostToDevice, s));
         CREATE_CHK(hipStreamSynchronize(s));
         if (launch_fp8_init_slots(h->slots, FP8_NSLOT, h->slot_targets, s) != 0) { if (h->own_ws) hipFree(h->ws); delete h; return fail(-10, "fp8 slot init failed"); }
@@ -1276,9 +1343,9 @@ int mrgan_set_weights(mrgan_handle* h, int net, int idx, const float* src, mrgan
     HIPCHK(hipMemcpy2DAsync(t->p, sizeof(float) * t->pcol, src, sizeof(float) * t->cols, sizeof(float) * t->cols, t->rows,
                             hipMemcpyDeviceToDevice, s));
     if (t->w16) hipLaunchKernelGGL(refresh_bf16_kernel, grid2d(t->prow, t->pcol), dim3(256), 0, s, t->p, t->w16, t->wt16, t->prow, t->pcol);
-    if (h->fp8 && net == MRGAN_NET_D && t->w16) {
+    if (h->fp8 && t->w16 && (net == MRGAN_NET_D || t == h->g[1].W)) {
         // fp8 copies of the discriminator's weights: the first pass only measures max |w|, the second stores with that scale
-        for (int pass = 0; pass < 2; ++pass) { CHK(fp8_refresh_weights(h, s)); CHK(fp8_update_scales(h, s)); }
+        for (int pass = 0; pass < 2; ++pass) { CHK(fp8_refresh_weights(h, net, s)); CHK(fp8_update_scales(h, s)); }
     }
     return 0;
 }

@@ -236,7 +236,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                                 v = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & (uint32_t)(-(int)((mbits >> r) & 1u)));
                             else if (act == ACT_SOFTPLUS) {
                                 float hv;
-                                if constexpr (STAGED) hv = (row < M && colin) ? Elem<T>::to_f32(htile[(row - row_blk) * bn + (col - col_blk)]) : 0.f;
+                                if (STAGED && htile) hv = (row < M && colin) ? Elem<T>::to_f32(htile[(row - row_blk) * bn + (col - col_blk)]) : 0.f;
                                 else hv = (row < M && colin) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : 0.f;
                                 // softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
                                 v *= fast_math ? one_minus_exp_neg_fast(hv) : -expm1f(-hv);
@@ -336,7 +336,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                                 const bool ok = row < M;
                                 const float v = ok ? keep[mi][ni][r] : 0.f;
                                 float hv;
-                                if constexpr (STAGED) hv = (ok && cok) ? Elem<T>::to_f32(htile[(row - row_blk) * bn + (col - col_blk)]) : mu;
+                                if (STAGED && htile) hv = (ok && cok) ? Elem<T>::to_f32(htile[(row - row_blk) * bn + (col - col_blk)]) : mu;
                                 else hv = (ok && cok) ? Elem<T>::to_f32(hprev[(long)row * e.ldh + col]) : mu;
                                 s1 += v; s2 = fmaf(v * (hv - mu), rstd, s2);
                             }

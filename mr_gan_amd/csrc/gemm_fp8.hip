@@ -403,9 +403,15 @@ int launch_gemm_fp8(int epi, const GemmArgs& g, hipStream_t s, const char** knam
         }
     } else if (epi == EPI_DX) {
         nm = big ? "gemm_fp8_kc_kernel<1, 256, 256>" : "gemm_fp8_kc_kernel<1, 128, 128>";
-        if (e.cs_mode != CS_NONE && e.cs_mode != CS_SUM) return -3;
-        if (out8) { if (e.act == ACT_RELU && mask) r = launch_fp8_var<EPI_DX, ACT_RELU, true>(g, s, big); }
-        else if (e.act == ACT_LINEAR) r = launch_fp8_var<EPI_DX, ACT_LINEAR, false>(g, s, big);
+        if (out8) {
+            if (e.cs_mode != CS_NONE && e.cs_mode != CS_SUM) return -3;
+            if (e.act == ACT_RELU && mask) r = launch_fp8_var<EPI_DX, ACT_RELU, true>(g, s, big);
+        } else if (e.act == ACT_LINEAR) {
+            // CS_SUM_XHAT (BatchNorm backward sums of the generator): the epilogue reads e.h from global memory
+            if (e.cs_mode == CS_SUM_XHAT && !(e.h && e.bn_mu && e.bn_rstd && e.cs2)) return -3;
+            if (e.cs_mode == CS_SUM_SQ) return -3;
+            r = launch_fp8_var<EPI_DX, ACT_LINEAR, false>(g, s, big);
+        }
     } else if (epi == EPI_SLAB) {
         nm = big ? "gemm_fp8_kc_kernel<2, 256, 256>" : "gemm_fp8_kc_kernel<2, 128, 128>";
         if (!e.slab) return -3;

@@ -422,12 +422,17 @@ class MRGANMirror(object):
             self.cal = [False, False]
             for _ in range(2):                       # mrgan_set_weights: the first pass only measures max |w|
                 self._refresh_w8()
+                self._refresh_gw8()
                 self.slots.update()
 
     # ---- fp8 mode ----------------------------------------------------------------------------------------
     def _refresh_w8(self):
         nl = len(self.d) // 2
         self.w8 = [self.slots.quant(bf16_round(self.d[2 * l]), ('w', l), 'e4m3') for l in range(nl - 1)]
+
+    def _refresh_gw8(self):
+        """the generator's second dense layer (the one wide product of the generator) also runs in fp8"""
+        self.gw8 = self.slots.quant(bf16_round(self.g[4]), ('gw',), 'e4m3')
 
     def _disc_fwd8(self, xin0, noise, kind):
         """one segment through dense 1..5 with e4m3 operands; xin0 = the bf16 noisy input rows"""
@@ -500,7 +505,11 @@ class MRGANMirror(object):
         h1q = q(h1)
         scale = gamma * rstd
         hbn = q(h1q * scale + (beta - mu * scale))
-        h2q = q(softplus(hbn @ q(W2) + b2))
+        if getattr(self, 'fp8', False):
+            hbn = self.slots.quant(hbn, ('gx',), 'e4m3')       # e4m3 copy of BN(h1): operand of G2's forward and weight gradient
+            h2q = q(softplus(hbn @ self.gw8 + b2))
+        else:
+            h2q = q(softplus(hbn @ q(W2) + b2))
         x = h2q @ q(W3) + b3
         xin = q(x + np.asarray(self.sigmas[0], x.dtype) * n0) if n0 is not None else q(x)
         return xin, dict(zq=zq, h1q=h1q, mu=mu, rstd=rstd, hbn=hbn, h2q=h2q, B=B)
@@ -627,8 +636,13 @@ class MRGANMirror(object):
         v = (dxf @ q(W3).T) * (-np.expm1(-gc['h2q']))                             # softplus'(pre) = 1 - exp(-h)
         db2 = v.sum(axis=0)
         dpre2 = q(v)
-        dW2 = gc['hbn'].T @ dpre2
-        v = dpre2 @ q(W2).T
+        if self.fp8:
+            dpre2 = self.slots.quant(dpre2, ('gg',), 'e5m2')
+            dW2 = gc['hbn'].T @ dpre2
+            v = dpre2 @ self.gw8.T
+        else:
+            dW2 = gc['hbn'].T @ dpre2
+            v = dpre2 @ q(W2).T
         xh = (gc['h1q'] - gc['mu']) * gc['rstd']
         dbeta = v.sum(axis=0)
         dgamma = (v * xh).sum(axis=0)
@@ -643,6 +657,7 @@ class MRGANMirror(object):
         loss, grads, _ = self.gen_grads(*a, **k)
         self.adam.apply(self.g, grads, 'g')
         if self.fp8:
+            self._refresh_gw8()
             self.slots.update()
         return loss
 
