@@ -84,6 +84,10 @@ struct FmArgs {
     void* dpre; int ldd; int rows;
     float* loss_out; float* accum;                        // step scalar + epoch accumulator (block 0 only)
     unsigned char* q8; int ldq8; Fp8Slot* q8_slot;        // fp8 mode: e5m2 copy of dpre (row-major), scaled by the slot; dpre may be null
+    int rb;                                               // rows per block (set by launch_fm)
+    // wide feature layers: the loss is assembled from per-column-block partials (lscratch[gridDim.x]) by the last block to
+    // arrive (*lcount: ticket, left at zero again) in a fixed order, instead of by one extra block that walks every column
+    float* lscratch; unsigned int* lcount;
 };
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s);
 

@@ -231,7 +231,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
 // Per-block partial gradients go to part[blk][...]; reduce_partials_kernel folds them to <= 8 slabs.
 // =========================================================================================
 constexpr int HR = HEAD_ROWS;
-template <typename T>
+// Q8 (fp8 mode): dpre leaves as e5m2 copies (row-major + transposed) packed from the fp32 values; a separate instantiation,
+// so the bf16 / fp32 kernels keep their rolled row loop and register count
+template <typename T, bool Q8 = false>
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float hl[];
     // the feature dimension is walked in chunks of CH <= 256 columns (one chunk for the reference's 250-wide layer)
@@ -392,10 +394,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
 #pragma unroll
             for (int c = 0; c < KMAX; ++c) { wj[c] = w_lds[j * KMAX + c]; dw[c] = 0.f; }
             float dbf = 0.f;
-            uint32_t qw[HR / 4];
-            float q4[4];
-#pragma unroll
-            for (int rr = 0; rr < HR; ++rr) {
+            auto row_step = [&](int rr) -> float {
                 const float fv = f_lds[rr * LDF + j];
                 const f32x4 d0 = *(const f32x4*)(dl_lds + rr * KMAX), d1 = *(const f32x4*)(dl_lds + rr * KMAX + 4);
                 float dfe = 0.f;
@@ -407,36 +406,44 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
                 const float dp = (fv > 0.f) ? dfe : 0.f;
                 if (dpre && row_blk + rr < a.rows) dpre[(long)(row_blk + rr) * a.ldd + c0 + j] = Elem<T>::from_f32(dp);
                 dbf += dp;
-                if (a.q8_slot) {                  // (rows >= a.rows have dl == 0, hence dp == 0: zero bytes)
-                    q8_amax = fmaxf(q8_amax, fabsf(dp));
-                    q4[rr & 3] = dp;
-                    if ((rr & 3) == 3) qw[rr >> 2] = fp8_pack4<FP8_E5M2>(q4[0], q4[1], q4[2], q4[3], q8s);
-                }
-            }
-            if (a.q8_slot) {
-                if (q8t) {
-                    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+                return dp;
+            };
+            if constexpr (Q8) {
+                // 16 rows at a time: four dwords = 16 contiguous bytes of the transposed copy; the row-major copy trades bytes
+                // inside the lane quad (4 neighbouring columns; CH and the column stride are multiples of 4) and stores one
+                // dword per four rows.  Rows >= a.rows have dl == 0, hence dp == 0: zero bytes.
+                typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+                const int kq = t & 3;
+#pragma unroll 1
+                for (int k16 = 0; k16 < HR / 16; ++k16) {
+                    uint32_t qw[4];
 #pragma unroll
-                    for (int k = 0; k < HR / 16; ++k)
-                        *(u32x4_t*)(q8t + (long)(c0 + j) * a.ldq8t + row_blk + 16 * k) = (u32x4_t){qw[4 * k], qw[4 * k + 1], qw[4 * k + 2], qw[4 * k + 3]};
-                }
-                if (q8) {
-                    // row-major copy: the four columns of a lane quad trade bytes, then each lane stores one dword per four rows
-                    // (CH and the loop stride are multiples of 4, so a quad is always inside the loop together)
-                    const int kq = t & 3;
+                    for (int k = 0; k < 4; ++k) {
+                        float q4[4];
 #pragma unroll
-                    for (int k = 0; k < HR / 4; ++k) {
-                        const uint32_t w = quad_byte_transpose(qw[k]);
-                        if (row_blk + 4 * k + kq < a.rows) *(uint32_t*)(q8 + (long)(row_blk + 4 * k + kq) * a.ldq8 + c0 + j - kq) = w;
+                        for (int i = 0; i < 4; ++i) { q4[i] = row_step(16 * k16 + 4 * k + i); q8_amax = fmaxf(q8_amax, fabsf(q4[i])); }
+                        qw[k] = fp8_pack4<FP8_E5M2>(q4[0], q4[1], q4[2], q4[3], q8s);
+                        __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of the next four rows from being hoisted (registers)
+                    }
+                    if (q8t) *(u32x4_t*)(q8t + (long)(c0 + j) * a.ldq8t + row_blk + 16 * k16) = (u32x4_t){qw[0], qw[1], qw[2], qw[3]};
+                    if (q8) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t w = quad_byte_transpose(qw[k]);
+                            const int row = row_blk + 16 * k16 + 4 * k + kq;
+                            if (row < a.rows) *(uint32_t*)(q8 + (long)row * a.ldq8 + c0 + j - kq) = w;
+                        }
                     }
                 }
+            } else {
+                for (int rr = 0; rr < HR; ++rr) row_step(rr);
             }
             *(f32x4*)(part_row + (long)(c0 + j) * KMAX) = (f32x4){dw[0], dw[1], dw[2], dw[3]};
             *(f32x4*)(part_row + (long)(c0 + j) * KMAX + 4) = (f32x4){dw[4], dw[5], dw[6], dw[7]};
             part_row[a.off_dbf + c0 + j] = dbf;
         }
     }
-    if (a.q8_slot) fp8_amax_commit(a.q8_slot, q8_amax);
+    if constexpr (Q8) fp8_amax_commit(a.q8_slot, q8_amax);
 }
 
 // dst[g][i] = sum of src[p][i] over the partial rows p of group g (p = g, g + ngroups, ...)
@@ -463,7 +470,8 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
     __shared__ float scr[16][CB], sf[CB], sr[CB];
     const int t = threadIdx.x, col0 = blockIdx.x * CB;
     const float* cs_real = a.cs + (long)a.npart_fake * a.ldcs;
-    if (blockIdx.y == gridDim.y - 1) {
+    const bool dist_loss = a.lscratch != nullptr;
+    if (!dist_loss && blockIdx.y == gridDim.y - 1) {
         // the extra block row: block x == 0 produces the loss scalar, which needs every column.  Thread = 4 columns x
         // every 4th partial row, all loads independent, so this block is no slower than the row blocks.
         if (blockIdx.x != 0) return;
@@ -473,8 +481,22 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
         for (int c0 = 0; c0 < a.feat; c0 += 256) {
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
             if (c0 + q < a.feat) {
-                for (int p = pl; p < a.npart_fake; p += 4) d += *(const f32x4*)(a.cs + (long)p * a.ldcs + c0 + q);
-                for (int p = pl; p < a.npart_real; p += 4) d -= *(const f32x4*)(cs_real + (long)p * a.ldcs + c0 + q);
+                // four independent partial sums per stream: the loads of a wide feature layer's 128 partial rows overlap
+                // instead of forming one dependent chain (this single block was the kernel's critical path: 0.27 ms)
+                f32x4 s0 = d, s1 = d, s2 = d, s3 = d;
+                int p = pl;
+                for (; p + 12 < a.npart_fake; p += 16) {
+                    s0 += *(const f32x4*)(a.cs + (long)p * a.ldcs + c0 + q); s1 += *(const f32x4*)(a.cs + (long)(p + 4) * a.ldcs + c0 + q);
+                    s2 += *(const f32x4*)(a.cs + (long)(p + 8) * a.ldcs + c0 + q); s3 += *(const f32x4*)(a.cs + (long)(p + 12) * a.ldcs + c0 + q);
+                }
+                for (; p < a.npart_fake; p += 4) s0 += *(const f32x4*)(a.cs + (long)p * a.ldcs + c0 + q);
+                p = pl;
+                for (; p + 12 < a.npart_real; p += 16) {
+                    s0 -= *(const f32x4*)(cs_real + (long)p * a.ldcs + c0 + q); s1 -= *(const f32x4*)(cs_real + (long)(p + 4) * a.ldcs + c0 + q);
+                    s2 -= *(const f32x4*)(cs_real + (long)(p + 8) * a.ldcs + c0 + q); s3 -= *(const f32x4*)(cs_real + (long)(p + 12) * a.ldcs + c0 + q);
+                }
+                for (; p < a.npart_real; p += 4) s0 -= *(const f32x4*)(cs_real + (long)p * a.ldcs + c0 + q);
+                d = (s0 + s1) + (s2 + s3);
             }
             __syncthreads();
             *(f32x4*)(dsc + pl * 256 + q) = d;
@@ -498,6 +520,25 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
     if (t < CB) {
         const float diff = (col0 + t < a.feat_valid) ? (sf[t] - sr[t]) / a.count : 0.f;
         gj_lds[t] = a.grad_scale * 2.0f / ((float)a.feat_valid * a.count) * diff;
+        if (dist_loss && blockIdx.y == 0) {
+            // this column block's share of sum_j diff_j^2 (one wave: CB == 64), then the ticket
+            const float part = wave_sum(diff * diff);
+            __shared__ unsigned int ticket;
+            if (t == 0) {
+                a.lscratch[blockIdx.x] = part;
+                __threadfence();
+                ticket = atomicAdd(a.lcount, 1u);
+            }
+            if (t == 0 && ticket == gridDim.x - 1) {
+                __threadfence();
+                float tot = 0.f;
+                for (unsigned int i = 0; i < gridDim.x; ++i) tot += ((volatile float*)a.lscratch)[i];      // fixed order: reproducible
+                const float loss = tot / (float)a.feat_valid;
+                if (a.loss_out) *a.loss_out = loss;
+                if (a.accum) *a.accum += loss;
+                *a.lcount = 0u;
+            }
+        }
     }
     __syncthreads();
     const int cg = t & 7, rl = t >> 3, c0 = col0 + cg * 8;
@@ -505,8 +546,8 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
     T* dpre = (T*)a.dpre;
     const float q8s = a.q8_slot ? a.q8_slot->scale : 1.f;
     float q8_amax = 0.f;
-    const int r1 = min(a.rows, (int)(blockIdx.y + 1) * RB);
-    for (int r = blockIdx.y * RB + rl; r < r1; r += 32) {
+    const int r1 = min(a.rows, (int)(blockIdx.y + 1) * a.rb);
+    for (int r = blockIdx.y * a.rb + rl; r < r1; r += 32) {
         // lane-native mask layout (gemm.h): per (32-row block, column) two u16 words, one per lane half
         const int rr = r & 31, half = (rr >> 2) & 1, bit = (rr & 3) | ((rr >> 3) << 2);
         const uint32_t* mp = (const uint32_t*)(a.mask + ((long)(r >> 5) * a.ldm + c0) * 2);
@@ -726,7 +767,17 @@ int launch_head(int bf16, const HeadArgs& a, hipStream_t s) {
     if ((a.feat % 64) != 0 || a.classes > KMAX) return -3;
     const size_t smem = sizeof(float) * ((size_t)HR * (ch + 8) + (size_t)ch * KMAX + HR * KMAX + 16);
     dim3 grid(ceil_div(a.rows, HR), a.nseg);
-    LAUNCH_T(head_kernel, grid, dim3(256), smem, s, a);
+    if (a.q8_slot) {
+        if (!bf16 || !(a.q8 || a.q8t)) return -3;
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)head_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return -2;
+            attr = true;
+        }
+        MRGAN_LAUNCH((head_kernel<__bf16, true>), grid, dim3(256), smem, s, a);
+    } else {
+        LAUNCH_T(head_kernel, grid, dim3(256), smem, s, a);
+    }
     RET_LAUNCH;
 }
 
@@ -737,8 +788,16 @@ int launch_reduce_partials(const float* src, int nsrc, long stride, int n, int n
 
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s) {
     if ((a.feat % 8) != 0) return -3;
-    dim3 grid(ceil_div(a.feat, CB), ceil_div(a.rows, RB) + 1);      // + the loss block row
-    LAUNCH_T(fm_kernel, grid, dim3(256), 0, s, a);
+    // every block first folds the column partial sums of its 64 columns (all row tiles): with a wide feature layer that
+    // prologue would be repeated by thousands of 64-row blocks (0.34 ms at 4096 features x 8192 rows), so blocks take more rows
+    // once ~512 of them exist
+    FmArgs b = a;
+    const int gx = ceil_div(a.feat, CB);
+    b.rb = std::max(RB, (int)round_up(ceil_div(a.rows, std::max(1, 512 / gx)), 32));
+    const bool dist = gx >= 16 && a.lscratch && a.lcount;
+    if (!dist) { b.lscratch = nullptr; b.lcount = nullptr; }
+    dim3 grid(gx, ceil_div(a.rows, b.rb) + (dist ? 0 : 1));      // + the loss block row of the narrow form
+    LAUNCH_T(fm_kernel, grid, dim3(256), 0, s, b);
     RET_LAUNCH;
 }
 

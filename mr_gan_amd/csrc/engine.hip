@@ -131,6 +131,7 @@ struct mrgan_handle {
     unsigned char *hbn8, *hbn8t, *dp2g8, *dp2g8t, *gw8, *gw8t;      // generator layer G2: BN(h1) [2][S][N1], dpre2 [S][N2], W2
     int gen_seg;                                                  // segment the generator views point at (set_gen_view)
     Fp8Slot* slots; float* slot_targets; float* accum_save;
+    float* fm_scratch; unsigned int* fm_count;       // feature-matching loss partials of a wide feature layer (aux_kernels.hip)
     bool chain_ok, use_chain;            // the 256-wide tail of the discriminator runs as row-block chain launches (gemm_chain.hip)
     int tune_kc_cfg, tune_bits, tune_pair_gen;      // mrgan_set_tuning
     int ablate;                                      // mrgan_debug_ablate (timing experiments)
@@ -316,6 +317,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     }
     h->dxfake = act(S, h->Dp); h->dpre2g = act(S, h->g[1].Np); h->dhbn = act(S, N1p); h->dpre1g = act(S, N1p);
     h->logits = a.take<float>(3 * (size_t)S * KMAX);
+    h->fm_scratch = a.take<float>(ceil_div(h->Fp, 64)); h->fm_count = a.take<unsigned int>(4);
 
     // ---- partial sums ----------------------------------------------------------------------------
     h->cs_bn1 = a.take<float>(2 * (size_t)tm * N1p); h->cs_bn2 = a.take<float>(2 * (size_t)tm * N1p);
@@ -1060,6 +1062,7 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
         f.ldcs = h->Fp; f.count = h->stat_count; f.grad_scale = h->fm_scale; f.feat = h->Fp; f.feat_valid = h->F;
         f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B;
         f.loss_out = h->step_out + 3; f.accum = h->accum + 3;
+        f.lscratch = h->fm_scratch; f.lcount = h->fm_count;
         if (h->fp8) { f.dpre = nullptr; f.q8 = h->g8[4]; f.ldq8 = h->Fp; f.q8_slot = h->slots + slot_g(1, 4); }
         if (h->use_chain) {
             // feature-matching gradient -> dX through D5 D4 D3 on the generated rows, one launch
