@@ -110,6 +110,16 @@ int mrgan_disc_step(mrgan_handle* h, const mrgan_disc_args* a, int phase_first, 
 /* out1_host (optional): loss_gen */
 int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int phase_first, int phase_last,
                    float* out1_host, mrgan_stream stream);
+/* fp8 mode, phase-wise callers only (data-parallel hosts; whole-sub-step callers need none of this: mrgan_disc_step /
+ * mrgan_gen_step / mrgan_train_pair settle the scales themselves).  The delayed scales of a sub-step kind (0 = D, 1 = G) are
+ * settled by running its forward + backward phases (D_GEN .. D_MAIN, or G_GEN .. G_BWD, with the host's exchanges in between)
+ * MRGAN_FP8_DRY_PASSES times WITHOUT the update phases, between BEGIN and DONE and each followed by END_PASS.  A handle
+ * with synchronised statistics refuses a phase-wise first sub-step that was not calibrated this way. */
+enum { MRGAN_FP8_DRY_PASSES = 5 };
+enum { MRGAN_FP8_CAL_QUERY = 0, MRGAN_FP8_CAL_BEGIN = 1, MRGAN_FP8_CAL_END_PASS = 2, MRGAN_FP8_CAL_DONE = 3 };
+/* QUERY returns 1 (calibrated, or not an fp8 handle) or 0; the other actions return 0 or a negative status */
+int mrgan_fp8_calibration(mrgan_handle* h, int kind, int action, mrgan_stream stream);
+
 /* Supervised baseline on the same discriminator stack (mr_nn.py:101-118): one Keras train_on_batch of the 6-layer MLP with
  * GaussianNoise, loss = mse against the one-hot label, Adam with the handle's lr / beta_1 (Keras defaults 0.001 / 0.9: set
  * them in mrgan_config).  Uses the D network and its Adam slots only; one iteration counter step per call.  A handle should

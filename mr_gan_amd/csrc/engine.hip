@@ -68,7 +68,7 @@ struct Dense {
 struct ProfRec { int cat; hipEvent_t start, stop; double flops, bytes; };      // device-side begin / end of one kernel (MRGAN_LAUNCH)
 
 // fp8 scaling slots: kind 0 = D sub-step, 1 = G sub-step; X = activations (e4m3), G = gradients (e5m2), W = weights (e4m3)
-constexpr int FP8_NSLOT = 28, FP8_DRY_PASSES = 5;
+constexpr int FP8_NSLOT = 28, FP8_DRY_PASSES = MRGAN_FP8_DRY_PASSES;
 inline int slot_x(int kind, int l) { return kind * 10 + l; }
 inline int slot_g(int kind, int l) { return kind * 10 + 5 + l; }
 inline int slot_w(int l) { return 20 + l; }
@@ -1401,6 +1401,8 @@ int mrgan_disc_step(mrgan_handle* h, const mrgan_disc_args* a, int p0, int p1, f
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     if (p1 < 0) p1 = MRGAN_D_NPHASES - 1;
+    if (h->fp8 && p0 == 0 && !h->fp8_cal[0] && p1 < MRGAN_D_NPHASES - 1 && h->sync_stats)
+        return fail(-3, "fp8 with synchronised statistics: a phase-wise host runs the calibration passes itself (mrgan_fp8_calibration)");
     if (h->fp8 && p0 == 0 && !h->fp8_cal[0]) {
         // first D sub-step of an fp8 handle: dry passes (forward + backward, no update) settle the delayed scales, one
         // layer of the gradient chain per pass
@@ -1424,6 +1426,8 @@ int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int p0, int p1, flo
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     if (p1 < 0) p1 = MRGAN_G_NPHASES - 1;
+    if (h->fp8 && p0 == 0 && !h->fp8_cal[1] && p1 < MRGAN_G_NPHASES - 1 && h->sync_stats)
+        return fail(-3, "fp8 with synchronised statistics: a phase-wise host runs the calibration passes itself (mrgan_fp8_calibration)");
     if (h->fp8 && p0 == 0 && !h->fp8_cal[1]) {
         // same for the G sub-step's tensors (its own slots: the feature-matching gradient has another scale than the D loss's);
         // the feature-matching kernel adds its loss to the epoch accumulator, which the dry passes must leave alone
@@ -1441,6 +1445,25 @@ int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int p0, int p1, flo
         HIPCHK(hipStreamSynchronize(s));
     }
     return 0;
+}
+
+int mrgan_fp8_calibration(mrgan_handle* h, int kind, int action, mrgan_stream stream) {
+    if (!h || kind < 0 || kind > 1) return fail(-1, "fp8_calibration: bad handle or kind");
+    hipStream_t s = (hipStream_t)stream;
+    if (action == MRGAN_FP8_CAL_QUERY) return (!h->fp8 || h->fp8_cal[kind] == 1) ? 1 : 0;
+    if (!h->fp8) return 0;
+    switch (action) {
+        case MRGAN_FP8_CAL_BEGIN:
+            h->fp8_cal[kind] = 2;                     // in progress: the phases run as they are
+            if (kind == 1) HIPCHK(hipMemcpyAsync(h->accum_save, h->accum, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+            return 0;
+        case MRGAN_FP8_CAL_END_PASS: CHK(fp8_update_scales(h, s)); return 0;
+        case MRGAN_FP8_CAL_DONE:
+            if (kind == 1) HIPCHK(hipMemcpyAsync(h->accum, h->accum_save, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+            h->fp8_cal[kind] = 1;
+            return 0;
+        default: return fail(-1, "fp8_calibration: unknown action %d", action);
+    }
 }
 
 int32_t mrgan_logmel_frames(int64_t n_samples) { return n_samples > 0 ? logmel_frames((long)n_samples) : 0; }
@@ -1493,7 +1516,7 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
         h->gen_ready = 0;
         return rr;
     };
-    if (!want_graph || (h->fp8 && !(h->fp8_cal[0] && h->fp8_cal[1]))) return both();     // (the calibrating first pair runs eagerly)
+    if (!want_graph || (h->fp8 && !(h->fp8_cal[0] == 1 && h->fp8_cal[1] == 1))) return both();     // (the calibrating first pair runs eagerly)
     // A pair flips the state slot twice, so every kernel argument is identical on every replay as long as
     // the slot parity and the caller's pointers are those of the capture.
     if (h->graph_ready && (h->graph_cur != h->cur || memcmp(&h->graph_d, d, sizeof *d) != 0 || memcmp(&h->graph_g, g, sizeof *g) != 0)) {

@@ -49,6 +49,9 @@ class EngineBackend(PhaseBackend):
     def pair_hint(self, on=True):
         self.engine.pair_hint(on)
 
+    def fp8_calibration(self, kind, action):
+        return self.engine.fp8_calibration(kind, action)
+
 
 class DataParallel(object):
     """grad_dtype: None (default) all-reduces the flat gradient buffers in fp32 -- replicas then reproduce the one-GPU step up
@@ -78,8 +81,38 @@ class DataParallel(object):
         else:
             dist.all_reduce(r, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _calibrate(self, kind, run_pass):
+        """fp8 engines: the first sub-step of a kind is preceded by dry passes (forward + backward phases WITH the statistic
+        exchanges, no gradient exchange, no update) that settle the delayed scales (include/mrgan_abi.h)"""
+        cal = getattr(self.backend, "fp8_calibration", None)
+        if cal is None or cal(kind, E.Engine.FP8_CAL_QUERY):
+            return
+        cal(kind, E.Engine.FP8_CAL_BEGIN)
+        for _ in range(E.Engine.FP8_DRY_PASSES):
+            run_pass()
+            cal(kind, E.Engine.FP8_CAL_END_PASS)
+        cal(kind, E.Engine.FP8_CAL_DONE)
+
+    def _disc_fwd_bwd(self, args):
+        b = self.backend
+        b.disc_phase(args, E.D_GEN)
+        if self.exact:
+            self._allreduce(E.REGION_BN_STATS)
+        b.disc_phase(args, E.D_MAIN)
+
+    def _gen_fwd_bwd(self, args, stats_done):
+        b = self.backend
+        b.gen_phase(args, E.G_GEN)
+        if self.exact and not stats_done:
+            self._allreduce(E.REGION_BN_STATS)
+        b.gen_phase(args, E.G_FEAT)
+        if self.exact:
+            self._allreduce(E.REGION_FM_MOMENTS)
+        b.gen_phase(args, E.G_BWD)
+
     def disc_step(self, args):
         b = self.backend
+        self._calibrate(0, lambda: self._disc_fwd_bwd(args))
         b.disc_phase(args, E.D_GEN)
         if self.exact:
             self._allreduce(E.REGION_BN_STATS)
@@ -89,6 +122,17 @@ class DataParallel(object):
 
     def gen_step(self, args, stats_done=False):
         b = self.backend
+        first = [True]
+
+        def dry():
+            # the first dry pass may still consume the paired generator forward of the D sub-step; later ones (and the real
+            # pass, if a dry pass ran) redo it and need their own BN exchange
+            self._gen_fwd_bwd(args, stats_done and first[0])
+            first[0] = False
+        cal = getattr(b, "fp8_calibration", None)
+        if cal is not None and not cal(1, E.Engine.FP8_CAL_QUERY):
+            self._calibrate(1, dry)
+            stats_done = False
         b.gen_phase(args, E.G_GEN)
         if self.exact and not stats_done:
             self._allreduce(E.REGION_BN_STATS)

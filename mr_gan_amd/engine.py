@@ -25,7 +25,7 @@ EXPORTS = [
     "mrgan_default_config", "mrgan_workspace_bytes", "mrgan_create", "mrgan_destroy", "mrgan_last_error",
     "mrgan_num_tensors", "mrgan_tensor_shape", "mrgan_set_weights", "mrgan_get_weights", "mrgan_get_slot",
     "mrgan_set_slot", "mrgan_get_iterations", "mrgan_set_iterations", "mrgan_disc_step", "mrgan_gen_step",
-    "mrgan_train_pair", "mrgan_sup_step", "mrgan_logmel", "mrgan_logmel_frames", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
+    "mrgan_train_pair", "mrgan_sup_step", "mrgan_fp8_calibration", "mrgan_logmel", "mrgan_logmel_frames", "mrgan_region", "mrgan_eval_error", "mrgan_predict_logits", "mrgan_read_metrics",
     "mrgan_pair_hint", "mrgan_set_tuning", "mrgan_debug_noise", "mrgan_debug_tr_probe", "mrgan_debug_gemm", "mrgan_profile_begin", "mrgan_profile_end", "mrgan_debug_ablate", "mrgan_debug_gemm_time", "mrgan_debug_buffer", "mrgan_debug_gemm_fp8",
 ]
 PROF_NAME_LEN = 96
@@ -261,6 +261,16 @@ class Engine(object):
         out = (C.c_float * 2)()
         _check(self.lib.mrgan_sup_step(self.handle, C.byref(args), out if want_outputs else None, _stream()))
         return tuple(out) if want_outputs else None
+
+    FP8_DRY_PASSES = 5
+    FP8_CAL_QUERY, FP8_CAL_BEGIN, FP8_CAL_END_PASS, FP8_CAL_DONE = 0, 1, 2, 3
+
+    def fp8_calibration(self, kind, action):
+        """phase-wise hosts (mr_gan_amd/dist.py): settle the fp8 scales of sub-step kind 0 (D) / 1 (G); see mrgan_abi.h"""
+        rc = self.lib.mrgan_fp8_calibration(self.handle, int(kind), int(action), _stream())
+        if rc < 0:
+            _check(rc)
+        return rc
 
     def train_pair(self, dargs, gargs):
         _check(self.lib.mrgan_train_pair(self.handle, C.byref(dargs), C.byref(gargs), _stream()))

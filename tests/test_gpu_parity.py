@@ -589,6 +589,42 @@ def test_two_rank_emulation_equals_full_batch():
         e.close()
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_fp8_phase_protocol_equals_whole_steps(exact):
+    """fp8 through the data-parallel phase protocol (mr_gan_amd/dist.py, one rank): with synchronised statistics the HOST runs
+    the calibration passes (mrgan_fp8_calibration) with the statistic exchanges in between, with per-shard statistics the
+    engine calibrates by itself; both must reproduce the whole-sub-step path exactly (same kernels, same order, same scales)."""
+    from mr_gan_amd import engine as E
+    from mr_gan_amd.dist import DataParallel, EngineBackend, dp_flags
+    D, B = 200, 128
+    case = Case(D=D, B=B, steps=2, device_z=True)
+    plain = _engine(D, B, 2, flags=E.FLAG_FLAT_GRADS)
+    phased = _engine(D, B, 2, flags=dp_flags(exact=exact))
+    if exact:                       # a phase-wise first sub-step that skipped the host-side calibration is refused
+        probe = _engine(D, B, 2, flags=dp_flags(exact=True))
+        _load(probe, case)
+        with pytest.raises(E.MrganError, match="calibration"):
+            probe.disc_step(E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0])), E.D_GEN, E.D_GEN, want_outputs=False)
+        probe.close()
+    for e in (plain, phased):
+        _load(e, case)
+    dp = DataParallel(EngineBackend(phased), exact=exact)
+    for t in range(case.steps):
+        da = E.Engine.disc_args(_t(case.x_lab[t]), _t(case.labels[t], torch.int32), _t(case.x_unl[t]))
+        ga = E.Engine.gen_args(_t(case.x_unl2[t]))
+        plain.disc_step(da, want_outputs=False)
+        plain.gen_step(ga, want_outputs=False)
+        dp.disc_step(da)
+        dp.gen_step(ga)
+    for net in (E.NET_D, E.NET_G):
+        for i, (a, b) in enumerate(zip(plain.get_weights(net), phased.get_weights(net))):
+            # (synchronised statistics take the BatchNorm sums through the finalize kernel: another summation order)
+            assert update_rel_err(b, a, (case.d0 if net == E.NET_D else case.g0)[i]) < (2e-2 if exact else 1e-6), (net, i)
+    assert phased.fp8_calibration(0, E.Engine.FP8_CAL_QUERY) == 1 and phased.fp8_calibration(1, E.Engine.FP8_CAL_QUERY) == 1
+    plain.close()
+    phased.close()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # host loop
 # ---------------------------------------------------------------------------------------------------------
