@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--hidden", type=int, default=0,
                     help="0 = the reference's layer widths (mr_gan.py:111-128); W = BASELINE configs[4]'s wide stack: five "
                          "discriminator layers and two generator layers of width W")
+    ap.add_argument("--g-hidden", type=int, default=0,
+                    help="with --hidden: width of the generator's two hidden layers (0 = the same width as the discriminator's; "
+                         "500 = BASELINE configs[4] read literally, \"wide D\": only the discriminator is widened)")
     ap.add_argument("--labeled-per-class", type=int, default=100)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
                     help="fp8: the discriminator's dense products on the fp8 matrix cores (BASELINE configs[4] asks for it with "
@@ -227,7 +230,7 @@ def main():
     cfg = E.default_config(D, B)
     g_hidden, d_hidden = (500, 500), (1000, 500, 250, 250, 250)
     if args.hidden:
-        g_hidden, d_hidden = (args.hidden,) * 2, (args.hidden,) * 5
+        g_hidden, d_hidden = (args.g_hidden or args.hidden,) * 2, (args.hidden,) * 5
         cfg.g_hidden[0], cfg.g_hidden[1] = g_hidden
         for i, w in enumerate(d_hidden):
             cfg.d_hidden[i] = w
@@ -400,7 +403,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s: synthetic N=%d x D=%d, K=6, batch %d per GPU, labeled %d/class; one step = "
                                "D sub-step (3B rows) + G sub-step (2B rows) + both Adam updates"
-                               % ("BASELINE configs[4] geometry (hidden %d x 5, generator %d x 2) on one GPU" % (args.hidden, args.hidden)
+                               % ("BASELINE configs[4] geometry (hidden %d x 5, generator %d x 2) on one GPU" % (args.hidden, args.g_hidden or args.hidden)
                                   if args.hidden else "BASELINE configs[1]", args.rows, D, B, args.labeled_per_class),
                    "global_batch": B * world, "rows_per_gpu": B, "parallelism": "dp%d" % world if world > 1 else "single",
                    "batch_statistics": ("local_stats (per shard)" if args.local_stats else "synced over ranks") if world > 1 else "n/a",
