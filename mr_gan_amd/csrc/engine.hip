@@ -688,7 +688,7 @@ int fp8_fwd(mrgan_handle* h, int l, int nb, bool want_t, bool fm_sums, hipStream
     e.cs_mode = (last && fm_sums) ? CS_SUM : CS_NONE; e.cs1 = h->cs_f; e.ldcs = L.Np;
     e.qa = h->slots + slot_x(kind, l); e.qb = h->slots + slot_w(l);
     if (!last) {
-        e.qo = h->slots + slot_x(kind, l + 1); e.q_fmt = FP8_E4M3;
+        e.qo = h->slots + slot_x(kind, l + 1);
         e.q8 = h->x8[l + 1]; e.q8_bs = (long)S * L.Np; e.ldq8 = L.Np;
         if (want_t) { e.q8t = h->x8t[l + 1]; e.q8t_bs = S; e.ldq8t = 3 * S; }
     }
@@ -709,7 +709,7 @@ int fp8_dx(mrgan_handle* h, int l, int nb, bool want_t, bool bias_sums, hipStrea
         e.act = ACT_RELU; e.n_valid = h->d[l - 1].N;
         e.mask = h->mask[l - 1]; e.mask_bs = (long)(S / 32) * h->ldm[l - 1] * 2; e.ldm = h->ldm[l - 1];
         e.cs_mode = bias_sums ? CS_SUM : CS_NONE; e.cs1 = h->cs_db[l - 1];
-        e.qo = h->slots + slot_g(kind, l - 1); e.q_fmt = FP8_E5M2;
+        e.qo = h->slots + slot_g(kind, l - 1);
         e.q8 = h->g8[l - 1]; e.q8_bs = (long)S * L.Kp; e.ldq8 = L.Kp;
         if (want_t) { e.q8t = h->g8t[l - 1]; e.q8t_bs = S; e.ldq8t = 3 * S; }
     } else {

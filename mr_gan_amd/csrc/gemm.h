@@ -43,10 +43,10 @@ struct Epi {
     float acc_scale;         // fp8 products: 1 / (scale of A * scale of B), applied to the accumulator (when qa is null)
     // fp8 path (gemm_fp8.hip).  Every fp8 tensor has a slot {amax of the last pass, power-of-two scale, 1 / scale}.
     const Fp8Slot* qa; const Fp8Slot* qb;     // operand slots: accumulator *= qa->inv_scale * qb->inv_scale
-    Fp8Slot* qo;                              // output slot: stored byte = fp8(v * qo->scale); max |v| -> qo->amax_bits
+    Fp8Slot* qo;                              // output slot: stored byte = fp8(v * qo->scale), e4m3 after a forward product,
+                                              // e5m2 after a dX product; max |v| -> qo->amax_bits
     void* q8; long q8_bs; int ldq8;           // fp8 copy of the output tile [batch][rows][ldq8]   (null: none)
     void* q8t; long q8t_bs; int ldq8t;        // transposed fp8 copy [cols][ldq8t], batch b at element offset b * q8t_bs
-    int q_fmt;                                // 0 = e4m3, 1 = e5m2
     int tune_kc_cfg;         // forward / dX tile config forced by mrgan_set_tuning (-1 = measured table)
     int tune_bits;           // TUNE_BIT_* of the handle
 };

@@ -3,7 +3,7 @@
 //
 //   FWD   Y  = act(X W + b) (+ noise)     A = X    e4m3 [rows][K]     Bt = W^T  e4m3 [N][K]
 //   DX    dX = (dY W^T) * relu'           A = dY   e5m2 [rows][N]     Bt = W    e4m3 [K][N]
-//   SLAB  dW = X^T dY                     A = X^T  e4m3 [K][rows]     Bt = dY^T e5m2 [N][rows]    (no split: rows >= 8192)
+//   SLAB  dW = X^T dY                     A = X^T  e4m3 [K][rows]     Bt = dY^T e5m2 [N][rows]    (no split-K: one fp32 slab)
 // All three are "A Bt^T" with the reduction index contiguous in both operands, so ONE kernel serves them: the producers
 // write every activation / gradient twice, row-major for the next FWD / DX and transposed for the SLAB product.
 //
@@ -14,9 +14,11 @@
 // LDS-DMA (buffer_load ... lds) into a 2-stage ring, one s_barrier per k-tile (128 reduction elements), persistent blocks in
 // XCD-aware tile order, 128x128 (4 waves) or 256x256 (8 waves of 128x64) blocks.
 //
-// Epilogue: the shared one of gemm.h (bias / relu / mask / GaussianNoise / column sums) assembles the bf16 tile in LDS;
-// quant_tile then writes it as fp8 (row-major and transposed, 16-byte stores) scaled by the output slot, and records max |v|.
-// The stored byte is therefore fp8(bf16(v)): the oracle's fp8 mirror rounds twice in the same way.
+// Epilogue: the shared one of gemm.h (bias / relu / mask / GaussianNoise / column sums).  With OUT8 it packs the fp8 output
+// straight from the fp32 accumulators (one rounding; the oracle's fp8 mirror does the same) into a transposed and a
+// row-major LDS byte image -- a lane's four consecutive rows of one column are one dword of the transposed image, the
+// row-major dword comes from a 4 x 4 byte transpose inside the lane quad -- which copy_tile writes out with 16-byte stores;
+// max |v| goes to the output slot.  Without OUT8 the output is the bf16 tile of the bf16 kernels.
 #include <algorithm>
 #include <string>
 
