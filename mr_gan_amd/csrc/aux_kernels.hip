@@ -607,11 +607,31 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     float w8_amax = 0.f;
     const int QL = nq <= 16 ? 16 : 64;                    // element-group slots; the other threads are slab lanes
     const int lanes = small ? 256 / QL : 1;
-#pragma unroll 1
-    for (int u = 0; u < (small ? 1 : 4); ++u) {
-        int r, tc, sl0 = 0;
-        if (small) { const int qi = t & (QL - 1); sl0 = t / QL; r = qi / qpr; tc = (qi - r * qpr) * 4; if (qi >= nq) r = tile.rows; }
-        else { r = (t >> 4) + 16 * u; tc = (t & 15) * 4; }
+    // update of one four-element group: Keras-2.0.9 Adam (eps outside the square root) + the bf16 / fp8 weight copies
+    auto update = [&](const f32x4 g, f32x4 m, f32x4 v, f32x4& pn, long off) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m[i] = a.b1 * m[i] + (1.0f - a.b1) * g[i];
+            v[i] = a.b2 * v[i] + (1.0f - a.b2) * g[i] * g[i];
+            pn[i] = pn[i] - lr_t * m[i] / (sqrtf(v[i]) + a.eps);
+        }
+        *(f32x4*)(tile.m + off) = m; *(f32x4*)(tile.v + off) = v; *(f32x4*)(tile.p + off) = pn;
+        if (tile.w16) {
+            bf16x4 w = {(__bf16)pn[0], (__bf16)pn[1], (__bf16)pn[2], (__bf16)pn[3]};
+            *(bf16x4*)(tile.w16 + off) = w;
+            if (tile.w8_slot) {           // fp8 mode: e4m3 copy of the bf16 values (what quant8_kernel would produce from w16)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pn[i] = (float)w[i]; w8_amax = fmaxf(w8_amax, fabsf(pn[i])); }
+                *(uint32_t*)(tile.w8 + off) = fp8_pack4<FP8_E4M3>(pn[0], pn[1], pn[2], pn[3], w8_scale);
+            }
+        }
+    };
+    if (small) {
+        int sl0 = t / QL;
+        const int qi = t & (QL - 1);
+        int r = qi / qpr;
+        const int tc = (qi - r * qpr) * 4;
+        if (qi >= nq) r = tile.rows;
         const bool valid = r < tile.rows && tc < tile.cols;
         const long off = (long)r * tile.ld + tc;
         f32x4 g = {0.f, 0.f, 0.f, 0.f}, pn = g;
@@ -619,38 +639,43 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
             if (a.mode == ADAM_FROM_FLAT) { if (sl0 == 0) g = *(const f32x4*)(tile.flat + off); }
             else g = adam_sum_slabs(tile.g + off, tile.slab_stride, sl0, lanes, tile.nslab);
         }
-        if (small) {                                      // combine the slab lanes
-            *(f32x4*)(tl + t * 4) = g;
-            __syncthreads();
-            if (sl0 == 0)
-                for (int k = 1; k < lanes; ++k) g += *(const f32x4*)(tl + (t + QL * k) * 4);
-        }
+        *(f32x4*)(tl + t * 4) = g;                        // combine the slab lanes
+        __syncthreads();
+        if (sl0 == 0)
+            for (int k = 1; k < lanes; ++k) g += *(const f32x4*)(tl + (t + QL * k) * 4);
         if (valid && sl0 == 0) {
             if (a.mode == ADAM_REDUCE_ONLY) *(f32x4*)(tile.flat + off) = g;
-            else {
-                f32x4 m = *(const f32x4*)(tile.m + off), v = *(const f32x4*)(tile.v + off);
-                pn = *(const f32x4*)(tile.p + off);
+            else { pn = *(const f32x4*)(tile.p + off); update(g, *(const f32x4*)(tile.m + off), *(const f32x4*)(tile.v + off), pn, off); }
+        }
+    } else {
+        // four row groups per thread; all their loads (gradient slabs, m, v, p) are issued before the first store (a load behind
+        // a store through another pointer is not hoisted by the compiler)
+        const int tc = (t & 15) * 4;
+        f32x4 g[4], m[4], v[4], pn[4];
+        long off[4];
+        bool valid[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    m[i] = a.b1 * m[i] + (1.0f - a.b1) * g[i];
-                    v[i] = a.b2 * v[i] + (1.0f - a.b2) * g[i] * g[i];
-                    pn[i] = pn[i] - lr_t * m[i] / (sqrtf(v[i]) + a.eps);
-                }
-                *(f32x4*)(tile.m + off) = m; *(f32x4*)(tile.v + off) = v; *(f32x4*)(tile.p + off) = pn;
-                if (tile.w16) {
-                    bf16x4 w = {(__bf16)pn[0], (__bf16)pn[1], (__bf16)pn[2], (__bf16)pn[3]};
-                    *(bf16x4*)(tile.w16 + off) = w;
-                    if (tile.w8_slot) {           // fp8 mode: e4m3 copy of the bf16 values (what quant8_kernel would produce from w16)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { pn[i] = (float)w[i]; w8_amax = fmaxf(w8_amax, fabsf(pn[i])); }
-                        *(uint32_t*)(tile.w8 + off) = fp8_pack4<FP8_E4M3>(pn[0], pn[1], pn[2], pn[3], w8_scale);
-                    }
-                }
+        for (int u = 0; u < 4; ++u) {
+            const int r = (t >> 4) + 16 * u;
+            valid[u] = r < tile.rows && tc < tile.cols;
+            off[u] = (long)r * tile.ld + tc;
+            g[u] = m[u] = v[u] = pn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (valid[u]) {
+                g[u] = a.mode == ADAM_FROM_FLAT ? *(const f32x4*)(tile.flat + off[u]) : adam_sum_slabs(tile.g + off[u], tile.slab_stride, 0, 1, tile.nslab);
+                if (a.mode != ADAM_REDUCE_ONLY) { m[u] = *(const f32x4*)(tile.m + off[u]); v[u] = *(const f32x4*)(tile.v + off[u]); pn[u] = *(const f32x4*)(tile.p + off[u]); }
             }
         }
-        if (tile.wt16) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tl[(tc + i) * 65 + r] = pn[i];
+        for (int u = 0; u < 4; ++u) {
+            const int r = (t >> 4) + 16 * u;
+            if (valid[u]) {
+                if (a.mode == ADAM_REDUCE_ONLY) *(f32x4*)(tile.flat + off[u]) = g[u];
+                else update(g[u], m[u], v[u], pn[u], off[u]);
+            }
+            if (tile.wt16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tl[(tc + i) * 65 + r] = pn[u][i];
+            }
         }
     }
     if (tile.wt16 && a.mode != ADAM_REDUCE_ONLY) {
