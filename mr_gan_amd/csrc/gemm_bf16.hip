@@ -364,7 +364,13 @@ __device__ __forceinline__ void ks_fast_body(const GemmArgs& g, const int bid) {
     const int ntn = (g.N + 127) / 128, ntm = (g.M + 127) / 128;
     const int tidx = xcd_tile(bid, ntn * ntm * g.splits);
     const int split = tidx / (ntn * ntm), rem = tidx - split * (ntn * ntm);
-    const int tile_m = rem / ntn, tile_n = rem - tile_m * ntn;
+    // wide layers: consecutive tiles (the 64 resident blocks of one XCD) form 8 x 8 patches instead of 2 x 32 strips, half
+    // the distinct operand columns per k-step into that XCD's L2 (as in the KC kernels)
+    int tile_m, tile_n;
+    if ((ntm & 7) == 0 && ntn >= 16) {
+        const int grp = rem / (8 * ntn), in = rem - grp * (8 * ntn);
+        tile_m = grp * 8 + (in & 7); tile_n = in >> 3;
+    } else { tile_m = rem / ntn; tile_n = rem - tile_m * ntn; }
     const int row_blk = tile_m * 128, col_blk = tile_n * 128;
     const int k_begin = split * g.kchunk;
     const int k_end = (g.e.ablate & 4) ? k_begin : min(g.K, k_begin + g.kchunk);
