@@ -205,6 +205,11 @@ int choose_splits(int group_tiles, int vrows) {
     return std::max(1, std::min(s, MAX_SLABS));
 }
 int dw_tiles(const Dense& L) { return ceil_div(L.Kp, 128) * ceil_div(L.Np, 128); }
+int fp8_dw_splits(int tiles, int rows) {
+    int s = 1;
+    while (s < 4 && tiles * s * 2 <= 512 && tiles >= 64 && (rows % (s * 2 * 128)) == 0 && rows / (s * 2) >= 2048) s *= 2;
+    return s;
+}
 
 int validate(const mrgan_config& c) {
     if (c.d_in < 1 || c.batch < 1) return fail(-1, "d_in and batch must be positive");
@@ -344,7 +349,9 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     for (int l = 0; l < 3; ++l) tiles_g += dw_tiles(h->g[l]);
     for (int l = 0; l < 5; ++l) {
         Dense& L = h->d[l];
-        L.splits = h->fp8 ? 1 : choose_splits(tiles_d, 2 * S + B);      // fp8: one product over all 3 S rows, no slabs to sum
+        // fp8: one product per layer over all 3 S rows; only a layer with too few 128 x 128 output tiles to fill the chip
+        // (the first layer of a wide stack) splits its reduction
+        L.splits = h->fp8 ? fp8_dw_splits(dw_tiles(L), 3 * S) : choose_splits(tiles_d, 2 * S + B);
         L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     for (int l = 0; l < 3; ++l) {
@@ -725,6 +732,7 @@ int fp8_dw(mrgan_handle* h, int l, int nseg, hipStream_t s) {
     const int S = h->S, kind = h->fp8_kind;
     GemmArgs g = fp8_args(h, L.Kp, L.Np, nseg * S, 1);
     g.tiles_m = ceil_div(L.Kp, 128);
+    g.splits = (nseg == 3) ? L.splits : 1; g.kchunk = nseg * S / g.splits;
     g.A = h->x8t[l]; g.a_si = 3 * S;
     g.B = h->g8t[l]; g.b_sj = 3 * S;
     g.e.qa = h->slots + slot_x(kind, l); g.e.qb = h->slots + slot_g(kind, l);

@@ -87,12 +87,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane >> 3, lp = lane & 7, lr = lane & 31, lh = lane >> 5;
     const int ntn = (g.N + BNT - 1) / BNT, ntm = (g.M + BM - 1) / BM;
-    const int ntiles = ntn * ntm * g.nbatch, nk = g.K / BKB;
+    // split-K (weight gradients of narrow layers only: too few output tiles to fill the chip): nbatch == 1, the reduction
+    // range is cut into g.splits chunks of g.kchunk elements, chunk s goes to fp32 slab s
+    const int nsplit = EPI == EPI_SLAB ? g.splits : 1;
+    const int ntiles = ntn * ntm * g.nbatch * nsplit, nk = (EPI == EPI_SLAB ? g.kchunk : g.K) / BKB;
     // undo the operand scales on the accumulator
     const float us = g.e.qa ? g.e.qa->inv_scale * g.e.qb->inv_scale : g.e.acc_scale;
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int tidx = xcd_tile(tl, ntiles);
-        const int batch = tidx / (ntn * ntm), rem = tidx - batch * (ntn * ntm);
+        const int bs = tidx / (ntn * ntm), rem = tidx - bs * (ntn * ntm);
+        const int batch = EPI == EPI_SLAB ? 0 : bs, split = EPI == EPI_SLAB ? bs : 0;
+        const int k0 = split * (EPI == EPI_SLAB ? g.kchunk : 0);
         // consecutive tiles (= the CUs of one XCD at any moment) form patches of 4 tile rows x 8 tile columns instead of
         // 2 x 16: a third less distinct operand data per k-step has to enter that XCD's L2
         int tile_m, tile_n;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
         };
         if (nk > 0) {
 #pragma unroll
-            for (int p = 0; p < NPIECE; ++p) issue_piece(0, 0, p);
+            for (int p = 0; p < NPIECE; ++p) issue_piece(k0, 0, p);
         }
         f32x16 acc[MR][NR];
 #pragma unroll
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
                     constexpr int STEPS = MR, PPS = (NPIECE + STEPS - 1) / STEPS;
 #pragma unroll
                     for (int q = 0; q < PPS; ++q)
-                        if (step * PPS + q < NPIECE) issue_piece((kt + 1) * BKB, nbuf, step * PPS + q);
+                        if (step * PPS + q < NPIECE) issue_piece(k0 + (kt + 1) * BKB, nbuf, step * PPS + q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 a_cur = a_next;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fp8_kc_kernel(const GemmArg
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= us;
         __syncthreads();
         if constexpr (EPI == EPI_SLAB) {
-            epilogue<__bf16, EPI_SLAB, MR, NR, WM, false, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BNT);
+            epilogue<__bf16, EPI_SLAB, MR, NR, WM, false, VAR>(acc, g, batch, split, tile_m, row_blk, col_blk, wm, wn, lane, (float*)lds, BNT);
         } else {
             // shared epilogue (bias / activation / mask / noise / column sums).  An fp8 output (e4m3 after a forward product,
             // e5m2 after a dX product) is packed straight from the accumulators into two LDS byte images and copied out;
@@ -324,7 +329,7 @@ int launch_fp8_cfg(const GemmArgs& g, hipStream_t s) {
     constexpr int OUT = (OUT8 ? BM * (BNT + 16) + BNT * (BM + 16) : BM * BNT * 2) + SCRATCH;
     constexpr int LDS = 2 * STAGE > OUT ? 2 * STAGE : OUT;
     static_assert(LDS <= 160 * 1024, "the ring exceeds the LDS of a CU");
-    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch;
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch * (EPI == EPI_SLAB ? g.splits : 1);
     dim3 grid(std::min(tiles, 256 * std::max(1, (160 * 1024) / LDS)));
     auto kern = gemm_fp8_kc_kernel<EPI, BM, BNT, WM, WN, VAR, OUT8>;
     static bool attr = false;
@@ -373,7 +378,9 @@ int launch_fp8_init_slots(Fp8Slot* slots, int n, const float* targets_dev, hipSt
 // g.A [M][K] bytes (a_si = row pitch in bytes), g.B = Bt [N][K] bytes (b_sj), K % 128 == 0; formats fixed by the product
 // (FWD e4m3 x e4m3, DX e5m2 x e4m3, SLAB e4m3 x e5m2)
 int launch_gemm_fp8(int epi, const GemmArgs& g, hipStream_t s, const char** kname) {
-    if ((g.K % BKB) != 0 || g.a_sk != 1 || g.b_sk != 1 || g.splits != 1) return -3;
+    if ((g.K % BKB) != 0 || g.a_sk != 1 || g.b_sk != 1 || g.splits < 1) return -3;
+    if (g.splits > 1 && (epi != EPI_SLAB || g.nbatch != 1 || (g.kchunk % BKB) != 0 || (long)g.kchunk * g.splits != g.K)) return -3;
+    if (epi == EPI_SLAB && g.splits == 1 && g.kchunk != g.K) return -3;
     if ((long)g.M * g.a_si >= (1L << 31) || (long)g.N * g.b_sj >= (1L << 31)) return -3;
     const Epi& e = g.e;
     if ((e.q8 || e.q8t) && !e.qo) return -3;
@@ -381,7 +388,7 @@ int launch_gemm_fp8(int epi, const GemmArgs& g, hipStream_t s, const char** knam
     if (e.q8t && ((e.ldq8t % 16) || (e.q8t_bs % 16))) return -3;
     if ((e.qa == nullptr) != (e.qb == nullptr)) return -3;
     // 256x256 blocks (8 waves of 128x64) once they fill the chip; e.tune_kc_cfg 1 / 3 force the small / large tile
-    const int t256 = ceil_div(g.M, 256) * ceil_div(g.N, 256) * g.nbatch;
+    const int t256 = ceil_div(g.M, 256) * ceil_div(g.N, 256) * g.nbatch * g.splits;
     // (measured at configs[4]: the K = 512 first layer runs 0.18 vs 0.31 ms per launch on the large tile -- its epilogue writes
     // three outputs per element and dominates, and the large tile halves the per-element epilogue overhead of the waves)
     bool big = g.K >= 512 && t256 >= 192 && (g.N % 256) == 0;

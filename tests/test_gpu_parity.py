@@ -480,6 +480,13 @@ def test_fp8_gradients_match_fp8_mirror(D, B, hidden):
                  loose=(0.9, 0.8, 0.6), **kw)
 
 
+def test_fp8_split_weight_gradient_of_a_narrow_first_layer():
+    """a first layer with few output tiles (512 x 2048) splits its fp8 weight-gradient product over the batch rows into two
+    fp32 slabs (engine.hip fp8_dw_splits); the other layers take the unsplit path"""
+    _grad_parity(512, 2048, 2, 'fp8', tol=5e-3, tol_loss=2e-3, eval_first=False, frac=0.7, loose=(0.9, 0.8, 0.6),
+                 d_hidden=(2048, 256, 256, 256, 256), g_hidden=(500, 500))
+
+
 def test_fp8_steps_match_fp8_mirror():
     """three (D, G) pairs in fp8 mode: losses and weights against the fp8 mirror's trajectory (delayed scales included)"""
     case = Case(D=400, B=128, steps=3)
