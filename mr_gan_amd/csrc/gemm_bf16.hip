@@ -620,7 +620,7 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         if (g.K >= 2048 && t256 >= 256 && (g.N % 256) == 0) cfg = 3;
         // long reductions into a narrow output (D2 forward: K = 1024, N = 512): three 64x128 blocks per CU with a
         // 2-stage ring hide the k-loop latency better than two 128x128 blocks (20.7 vs 21.7 us)
-        if (EPI == EPI_FWD && cfg == 1 && g.K >= 1024 && g.N <= 512) cfg = 5;
+        if (EPI == EPI_FWD && cfg == 1 && g.K >= 1024 && g.K < 2048 && g.N <= 512) cfg = 5;
     }
     if (cfg >= 2 && (g.N % 128) != 0) cfg = 0;
     if (cfg == 6 && (g.N % 256) != 0) cfg = 1;
