@@ -403,6 +403,7 @@ int launch_gemm_fp8(int epi, const GemmArgs& g, hipStream_t s, const char** knam
         nm = big ? "gemm_fp8_kc_kernel<0, 256, 256>" : "gemm_fp8_kc_kernel<0, 128, 128>";
         if (e.cs_mode != CS_NONE && e.cs_mode != CS_SUM) return -3;
         if (out8) {
+            if (e.cs_mode != CS_NONE) return -3;            // (the fp8-output epilogue carries column sums for dX only)
             if (e.act == ACT_RELU && noise && mask) r = launch_fp8_var<EPI_FWD, ACT_RELU | VAR_NOISE | VAR_MASK, true>(g, s, big);
         } else {
             if (e.act == ACT_RELU && !noise && mask) r = launch_fp8_var<EPI_FWD, ACT_RELU | VAR_MASK, false>(g, s, big);
