@@ -248,52 +248,48 @@ __global__ void to_fp8_kernel(const float* src, long lds_, unsigned char* dst, l
 }
 
 // bf16 [nb][rows][ld] -> fp8 (row-major and / or transposed) of v * slot->scale; max |v| -> slot.
-// Block = 256 rows x 64 columns: the transposed copy leaves through an LDS byte tile (row pitch 65: conflict-free in both
-// directions) so that every transposed row gets 256 contiguous bytes per block -- 16-byte pieces scattered at the transposed
-// pitch (a multiple of 8 KiB) ran at a seventh of this kernel's bandwidth.
-constexpr int Q8_ROWS = 256, Q8_PITCH = 65;
+// Block = 128 rows x 64 columns; thread = 4 rows x 8 columns, so a column's four rows are one dword of the transposed copy
+// without any byte shuffling.  The transposed dwords go through an LDS tile (pitch 33 dwords: conflict-free writes) and
+// leave as 16-byte pieces, 128 contiguous bytes of a transposed row per 8 lanes.
+constexpr int Q8_ROWS = 128, Q8_PITCH = 132;
 template <int FMT>
 __global__ __launch_bounds__(256) void quant8_kernel(const Quant8Args a) {
-    __shared__ unsigned char tq[Q8_ROWS * Q8_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char tq[64 * Q8_PITCH];
     const int t = threadIdx.x, batch = blockIdx.z;
     const int row0 = blockIdx.y * Q8_ROWS, col0 = blockIdx.x * 64;
     const float qs = a.slot->scale;
     const __bf16* src = a.src + (long)batch * a.src_bs;
-    const int cc = (t & 3) * 16;
+    const int cg = t & 7, rg = t >> 3;
+    float v[4][8];
     float amax = 0.f;
 #pragma unroll
-    for (int u = 0; u < Q8_ROWS / 64; ++u) {
-        const int r = (t >> 2) + 64 * u;
-        if (row0 + r >= a.prow) break;
-        float v[16];
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + rg * 4 + i;
+        bf16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < a.rows) x = *(const bf16x8*)(src + (long)r * a.ld + col0 + cg * 8);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = 0.f;
-        if (row0 + r < a.rows) {
-            const bf16x8 lo = *(const bf16x8*)(src + (long)(row0 + r) * a.ld + col0 + cc), hi = *(const bf16x8*)(src + (long)(row0 + r) * a.ld + col0 + cc + 8);
+        for (int c = 0; c < 8; ++c) { v[i][c] = (float)x[c]; amax = fmaxf(amax, fabsf(v[i][c])); }
+    }
+    if (a.dst) {
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { v[i] = (float)lo[i]; v[8 + i] = (float)hi[i]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
-        const u32x4 w = pack16<FMT>(v, qs);
-        if (a.dst) *(u32x4*)(a.dst + (long)batch * a.dst_bs + (long)(row0 + r) * a.ldd + col0 + cc) = w;
-        if (a.dstt) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tq[r * Q8_PITCH + cc + i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + rg * 4 + i;
+            if (r < a.prow)
+                *(u32x2*)(a.dst + (long)batch * a.dst_bs + (long)r * a.ldd + col0 + cg * 8) =
+                    (u32x2){fp8_pack4<FMT>(v[i][0], v[i][1], v[i][2], v[i][3], qs), fp8_pack4<FMT>(v[i][4], v[i][5], v[i][6], v[i][7], qs)};
         }
     }
     if (a.dstt) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *(uint32_t*)(tq + (cg * 8 + c) * Q8_PITCH + rg * 4) = fp8_pack4<FMT>(v[0][c], v[1][c], v[2][c], v[3][c], qs);
         __syncthreads();
-        // 16 lanes cover the 256 rows of one column (16 bytes each): 256 contiguous bytes of the transposed row
-        const int rg = t & 15;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int col = (t >> 4) + 16 * u, r0 = rg * 16;
+        for (int u = 0; u < 2; ++u) {
+            const int ch = t + 256 * u, col = ch >> 3, r0 = (ch & 7) * 16;
             if (row0 + r0 < a.prow) {
-                u32x4 w = {0u, 0u, 0u, 0u};
-#pragma unroll
-                for (int i = 0; i < 16; ++i) w[i >> 2] |= (uint32_t)tq[(r0 + i) * Q8_PITCH + col] << (8 * (i & 3));
-                *(u32x4*)(a.dstt + (long)(col0 + col) * a.lddt + (long)batch * a.dstt_bs + row0 + r0) = w;
+                const uint32_t* p = (const uint32_t*)(tq + col * Q8_PITCH + r0);
+                *(u32x4*)(a.dstt + (long)(col0 + col) * a.lddt + (long)batch * a.dstt_bs + row0 + r0) = (u32x4){p[0], p[1], p[2], p[3]};
             }
         }
     }
