@@ -277,6 +277,33 @@ def test_logmel_kernel_matches_numpy_restatement():
         log_melspectrogram_device(_t(rng.standard_normal((2, 1024))))
 
 
+def test_dataset_contact_mic_modalities_on_the_gpu(tmp_path):
+    """dataset() (mr_gan.py:23-71) with its default front end: the log-mel blocks of modalities 3 .. 6 come from ONE mrgan_logmel
+    launch over all trials and match the rows built with the numpy restatement (tests/test_dataset.py) within 0.02 dB"""
+    from mr_gan_amd import dataset
+    from tests.test_dataset import _oracle_logmel, _write_fake_mreo
+    _write_fake_mreo(str(tmp_path))
+    for mod, off in ((3, 0), (5, 1200)):
+        X, y = dataset(modalities=mod, data_dir=str(tmp_path))
+        Xo, yo = dataset(modalities=mod, data_dir=str(tmp_path), logmel_fn=_oracle_logmel)
+        assert X.shape == Xo.shape and np.array_equal(y, yo)
+        np.testing.assert_array_equal(X[:, :off], Xo[:, :off])
+        assert np.abs(X[:, off:] - Xo[:, off:]).max() < 0.02
+    objs = dataset(modalities=6, leaveObjectOut=True, data_dir=str(tmp_path))
+    assert len(objs) == 12 and np.array(objs['glass_obj1']['x']).shape == (3, 800 + 128 * 19)
+
+
+def test_mr_nn_function_end_to_end():
+    """mr_nn(X, y, ...) (mr_nn.py:69-119) on the MREO surrogate: split, scaling, labeled subset, 100-epoch-style fit (shortened),
+    whole-test-set error; fp32 and bf16 engines"""
+    from mr_gan_amd import synthetic_mreo
+    from mr_gan_amd.mr_nn import mr_nn
+    X, y, _ = synthetic_mreo(d=60, trials=40, sep=2.0)
+    for dtype in ('float32', 'bfloat16'):
+        err = mr_nn(X, y, percentlabeled=4, epochs=12, dtype=dtype, seed=11)
+        assert 0.0 <= err < 0.4, (dtype, err)              # chance is 0.83; 40 labeled rows per class, 12 epochs: ~0.2
+
+
 def test_device_z_matches_restatement():
     case = Case(D=16, B=52, steps=2, device_z=True)
     ref = case.run_oracle()
