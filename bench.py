@@ -31,6 +31,16 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}     # dense MFMA pea
 PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.29 TB/s measured by a float4 copy), same guide
 
 
+def source_sha():
+    """identity of the kernel sources a PMC summary under profiles/ was measured on (the GPU box has no .git)"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mr_gan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mr_gan_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def algorithmic_flops(B, D, g_hidden=(500, 500), d_hidden=(1000, 500, 250, 250, 250), K=6, nz=100):
     """2 FLOPs per MAC, GEMMs only, unpadded logical shapes.  Returns per-category FLOPs of
     one (D, G) step pair: forward / input-gradient / weight-gradient products."""
@@ -160,7 +170,7 @@ def cpu_baseline(args, X, xl, yl, budget_s=12.0):
             dt = time.time() - t0
         variants[name] = dict(value=n / dt, steps=n, seconds=round(dt, 1), threads=threads)
     best = max(variants, key=lambda k: variants[k]["value"])
-    return dict(value=variants[best]["value"], unit="steps/s", cores=variants[best]["threads"], kind="port",
+    return dict(value=variants[best]["value"], unit="steps/s", cores=variants[best]["threads"], host_cpu_count=os.cpu_count(), kind="port",
                 sample="the same workload (B=%d, D=%d), %d + %d steps in %.0f s: oracle/mrgan_oracle.py in numpy fp32 (noise drawn in the "
                        "loop, BLAS on all %d cores) and a PyTorch-CPU fp32 module with torch.set_num_threads(%d) and pre-generated noise; value = the faster (%s)"
                        % (B, D, variants["numpy_fp32"]["steps"], variants["torch_cpu_fp32"]["steps"],
@@ -195,6 +205,8 @@ def main():
                          "fewer small collectives per step). Default: they are all-reduced, so that W ranks at B/W reproduce the "
                          "one-GPU batch-B step")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="the timed block of --steps steps is repeated until this much time was timed (>= 5 repeats)")
+    ap.add_argument("--max-repeats", type=int, default=2000)
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (see mrgan_debug_ablate)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="mrgan_set_tuning experiments, e.g. --tune 1=3 (MRGAN_TUNE_KC_CFG = 3); results stay within rounding")
@@ -261,7 +273,7 @@ def main():
         # inputs resident in HBM before the timed region; epoch index streams as in mr_gan.py:189-195
         Xd = torch.from_numpy(X).to(dev)
         xld = torch.from_numpy(xl).to(dev)
-        total = args.warmup + args.steps + args.profile_steps + 4
+        total = max(args.warmup, args.steps, args.profile_steps) + 4
         n_rows = total * B
         prs = np.random.RandomState(11 + rank)
         inds = np.concatenate([tiled_permutation(prs, xl.shape[0], X.shape[0]) for _ in range(-(-n_rows // X.shape[0]))])[:n_rows]
@@ -281,26 +293,52 @@ def main():
             else:
                 eng.train_pair(dargs, gargs)
 
-        for _ in range(args.warmup):
-            step()
+        # Index streams hold max(warmup, steps, profile_steps) + 4 batches; the device-side batch counter is rewound before every
+        # block (outside the timed regions; the Adam iteration count runs on).
+        done = [0]
+
+        def rewind():
+            eng.set_iterations(2 * done[0], 0)
+
+        def run(n):
+            for _ in range(n):
+                step()
+            done[0] += n
+
+        def timed_block():
+            """EXACTLY --steps steps between barrier + synchronize brackets -> seconds on this rank"""
+            rewind()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            run(args.steps)
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        def over_ranks(ts):
+            if world == 1:
+                return list(ts)
+            t = torch.tensor(ts, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return [float(v) for v in t.tolist()]
+
+        run(args.warmup)
         torch.cuda.synchronize(dev)
         eng.read_metrics(reset=True)          # train_metrics below cover the timed steps only
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        # SURVEY.md 8(d): median of >= 5 repeats of the timed block, and >= 0.5 s of timed work in total whatever --steps is
+        blocks = over_ranks([timed_block()])
+        repeats = max(5, int(np.ceil(args.min_seconds / max(blocks[0], 1e-6))))
+        repeats = min(repeats, args.max_repeats)
+        blocks += over_ranks([timed_block() for _ in range(repeats - 1)])
+        elapsed = float(np.median(blocks))
+        timed_steps = repeats * args.steps
         metrics = eng.read_metrics(reset=True)
+        rewind()
 
         # ---- live per-kernel timing (separate pass, eager launches with hipEvent pairs) ----
         prof = None
@@ -370,37 +408,53 @@ def main():
     work = {k: v for k, v in prof.items() if v[2] > 0}
     dom = max(work, key=lambda k: work[k][0])
     all_ms = sum(v[0] for v in prof.values()) / P
-    # HBM bytes per launch of that kernel from the committed PMC summary (scripts/traffic.sh; separate --pmc passes, gfx950
-    # FETCH_SIZE correction applied there).  The summary is keyed by the full instantiation name (template arguments included)
-    # and carries the commit it was measured on; null when it has no row for exactly this instantiation.
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if world == 1 and not args.hidden and os.path.exists(tfile):
+    # HBM bytes per launch from the PMC summary under profiles/ (scripts/traffic.sh: separate --pmc passes, gfx950 FETCH_SIZE
+    # correction applied there), keyed by the full instantiation name.  The summary carries the hash of the kernel sources it
+    # was measured on: a summary of other sources is not evidence for this build and gives null.
+    traffic, step_traffic = None, None
+    tfile = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    if world == 1 and not args.hidden and args.dtype == "bf16" and B == 4096 and D == 512 and os.path.exists(tfile):
         tj = json.load(open(tfile))
-        row = tj.get("kernels", {}).get(dom)
-        if row:
-            traffic = {"hbm_bytes_per_launch": round(row["hbm_bytes_per_launch"]), "source": "profiles/r02_traffic.json",
-                       "measured_at_commit": tj.get("commit")}
-    roofline = line(*prof[dom], peak=peak_of(dom))
-    roofline.update({
-        "kernel": dom, "traffic": traffic,
-        "timing": "hipEvent (start, stop) pairs stamped at each kernel's begin and end on the launch stream "
-                  "(hipExtLaunchKernelGGL inside the library), profiled pass of %d steps after the timed region" % args.profile_steps,
-        "avg_launch_us": round(1e3 * prof[dom][0] / max(prof[dom][1], 1), 2),
-        "bound_rule": "mfma if algorithmic FLOP per algorithmic byte >= peak TFLOP/s / %.0f GB/s of the kernel's arithmetic (312 for bf16, 625 for fp8), else hbm" % PEAK_HBM_GBS,
+        if tj.get("source_sha") == source_sha():
+            rows = tj.get("kernels", {})
+            src = {"source": "profiles/r03_traffic.json", "source_sha": tj.get("source_sha"), "measured_at_commit": tj.get("commit")}
+            if dom in rows:
+                traffic = dict(hbm_bytes_per_launch=round(rows[dom]["hbm_bytes_per_launch"]), **src)
+            if all(k in rows for k in prof):
+                step_traffic = dict(hbm_bytes_per_step=round(sum(rows[k]["hbm_bytes_per_launch"] * v[1] / P for k, v in prof.items())), **src)
+    dom_line = line(*prof[dom], peak=peak_of(dom))
+    dom_line.update({"kernel": dom, "traffic": traffic, "avg_launch_us": round(1e3 * prof[dom][0] / max(prof[dom][1], 1), 2)})
+    step_tf = fl["total"] / (elapsed / args.steps) / 1e12
+    alg_bytes = sum(v[3] for v in prof.values()) / P
+    # headline: the WHOLE step against the MFMA roof (650 FLOP per algorithmic byte, MFMA side), with the dominant
+    # kernel's own line beside it
+    roofline = {
+        "bound": "mfma", "achieved": round(step_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(step_tf / peak, 4),
+        "traffic": step_traffic,
+        "scope": "whole (D, G) step: %.2f algorithmic GFLOP (SURVEY.md 8d: 2 FLOP per MAC, GEMMs only, unpadded shapes) over the median timed step"
+                 % (fl["total"] / 1e9),
+        "algorithmic_mb_per_step": round(alg_bytes / 1e6, 1),
+        "flop_per_byte": round(fl["total"] / alg_bytes, 1) if alg_bytes > 0 else None,
+        "dominant_kernel": dom_line,
+        "timing": "per-kernel figures: hipEvent (start, stop) pairs stamped at each kernel's begin and end on the launch stream "
+                  "(hipExtLaunchKernelGGL inside the library), profiled pass of %d steps after the timed region; algorithmic bytes = operands "
+                  "once + outputs once at logical shapes (no padding, no split-K slabs)" % args.profile_steps,
+        "bound_rule": "per kernel: mfma if algorithmic FLOP per algorithmic byte >= peak TFLOP/s / %.0f GB/s of its arithmetic (312 for bf16, 625 for fp8), else hbm" % PEAK_HBM_GBS,
         "families": {k: line(*v, peak=fam_peak[k]) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])},
-        "step": {"algorithmic_gflop": round(fl["total"] / 1e9, 2), "achieved": round(fl["total"] / (elapsed / args.steps) / 1e12, 2),
-                 "peak": peak, "unit": "TFLOP/s", "frac": round(fl["total"] / (elapsed / args.steps) / 1e12 / peak, 4),
-                 "launches": sum(v[1] for v in prof.values()) / P,
+        "step": {"algorithmic_gflop": round(fl["total"] / 1e9, 2), "launches": sum(v[1] for v in prof.values()) / P,
                  "kernel_ms": {k: round(v[0] / P, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
                  "kernel_launches": {k: v[1] / P for k, v in prof.items()},
                  "all_kernels_ms": round(all_ms, 4)},
-    })
+    }
     out = {
         "metric": "GAN train steps/sec (labeled+unlabeled+G) at batch 4096", "value": round(value, 2), "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
+        "repeats": repeats, "timed_steps_total": timed_steps,
+        "timing": "median over %d repeats of a block of exactly %d steps, each block between barrier + synchronize brackets "
+                  "(max over ranks per block); ms per step of the blocks: min %.4f / median %.4f / max %.4f"
+                  % (repeats, args.steps, 1e3 * min(blocks) / args.steps, ms_per_step, 1e3 * max(blocks) / args.steps),
         "config": {"workload": "%s: synthetic N=%d x D=%d, K=6, batch %d per GPU, labeled %d/class; one step = "
                                "D sub-step (3B rows) + G sub-step (2B rows) + both Adam updates"
                                % ("BASELINE configs[4] geometry (hidden %d x 5, generator %d x 2) on one GPU" % (args.hidden, args.g_hidden or args.hidden)
@@ -409,8 +463,8 @@ def main():
                    "batch_statistics": ("local_stats (per shard)" if args.local_stats else "synced over ranks") if world > 1 else "n/a",
                    "launch": "eager phases + RCCL all-reduce (%s gradients)" % args.grad_dtype if world > 1 else ("eager" if args.no_graph else "hipGraph replay")},
         "roofline": roofline,
-        "train_metrics": {"mean_loss_lab": metrics[0] / args.steps, "mean_loss_unl": metrics[1] / args.steps,
-                          "mean_train_err": metrics[2] / args.steps, "mean_loss_gen": metrics[3] / args.steps},
+        "train_metrics": {"mean_loss_lab": metrics[0] / timed_steps, "mean_loss_unl": metrics[1] / timed_steps,
+                          "mean_train_err": metrics[2] / timed_steps, "mean_loss_gen": metrics[3] / timed_steps},
     }
     if world == 1 and not args.no_cpu_baseline and not args.hidden:
         out["cpu_baseline"] = cpu_baseline(args, X, xl, yl)

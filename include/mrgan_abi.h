@@ -11,8 +11,10 @@
  * from mrgan_last_error() (thread-local).  Nothing throws across the ABI.  All pointers named *_dev are device
  * pointers (HBM); the caller owns inputs and outputs, the handle owns weights, optimiser state and workspace.
  * Calls are asynchronous on `stream` unless a host output pointer is passed (then the call synchronises the
- * stream before returning).  One handle per device; a handle is not thread-safe; no global state (tuning and the
- * diagnostic switches of mrgan_debug.h are per handle; nothing reads the environment).
+ * stream before returning).  One handle per device; a handle is not thread-safe.  Training state lives in the handle only
+ * (tuning and the diagnostic switches of mrgan_debug.h are per handle; nothing reads the environment); the library keeps two
+ * process-wide caches, both keyed by device id and safe to share between threads: which kernels have had their LDS limit
+ * raised on a device, and the mel filter banks of mrgan_logmel per (device, sr, n_mels).
  * No torch types appear here: the Python host passes tensor.data_ptr() and the raw hipStream_t.
  */
 #ifndef MRGAN_ABI_H
@@ -134,7 +136,8 @@ typedef struct mrgan_sup_args {
 int mrgan_sup_step(mrgan_handle* h, const mrgan_sup_args* a, float* out2_host, mrgan_stream stream);
 
 /* Log-mel front end of the contact-microphone modality (mr_gan.py:42-47: librosa.feature.melspectrogram(y, sr, n_mels=128)
- * followed by librosa.logamplitude(S, ref_power=np.max); n_fft 2048, hop 512, Slaney mel basis, -80 dB floor).  Stateless.
+ * followed by librosa.logamplitude(S, ref_power=np.max); n_fft 2048, hop 512, Slaney mel basis, -80 dB floor).  No handle:
+ * the only state is the cached filter bank per (device, sr, n_mels), built on first use under a mutex.
  * y_dev: n_trials rows of n_samples float32 (pitch ld_y); out_dev: n_trials rows of n_mels * mrgan_logmel_frames(n_samples)
  * float32, mel-major like log_S.flatten() (pitch ld_out). */
 int32_t mrgan_logmel_frames(int64_t n_samples);

@@ -794,10 +794,10 @@ int launch_head(int bf16, const HeadArgs& a, hipStream_t s) {
     dim3 grid(ceil_div(a.rows, HR), a.nseg);
     if (a.q8_slot) {
         if (!bf16 || !(a.q8 || a.q8t)) return -3;
-        static bool attr = false;
-        if (!attr) {
+        static DeviceOnce attr;
+        if (attr.first()) {
             if (hipFuncSetAttribute((const void*)head_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return -2;
-            attr = true;
+            attr.mark();
         }
         MRGAN_LAUNCH((head_kernel<__bf16, true>), grid, dim3(256), smem, s, a);
     } else {

@@ -4,6 +4,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace mrgan {
 
 // Every kernel of the step is launched through MRGAN_LAUNCH.  Normally that is hipLaunchKernelGGL; while the library's
@@ -20,6 +22,22 @@ extern thread_local LaunchTimer g_launch_timer;
             hipExtLaunchKernelGGL(kern, grid, block, lds, stream, lt_.start, lt_.stop, 0, __VA_ARGS__);                \
         } else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                        \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: each launcher keeps one bit per device id, so a process
+// that builds handles on several GPUs sets it on each of them (thread-safe: the set is idempotent, the bit is an atomic or)
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return true;
+        const unsigned long long bit = 1ull << (dev & 63);
+        return (done.load(std::memory_order_relaxed) & bit) == 0;
+    }
+    void mark() {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+    }
+};
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

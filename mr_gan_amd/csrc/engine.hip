@@ -466,17 +466,20 @@ void prof_done(mrgan_handle* h, const char* name, double flops, double bytes = 0
 // ------------------------------------------------------------------------------------------------
 // GEMM call sites
 // ------------------------------------------------------------------------------------------------
-int run_gemm(mrgan_handle* h, int epi, const GemmArgs& g, double algo_flops, hipStream_t s) {
+// algo_flops / algo_bytes: the ALGORITHMIC work of the product: logical, unpadded shapes, 2 FLOP per MAC,
+// operands read once + outputs written once -- no padding, no split-K slabs, no re-reads
+int run_gemm(mrgan_handle* h, int epi, const GemmArgs& g, double algo_flops, double algo_bytes, hipStream_t s) {
     const char* kname = "gemm";
     prof_arm(h);
     const int r = h->bf16 ? launch_gemm_bf16(epi, g, s, &kname) : launch_gemm_f32(epi, g, s, &kname);
-    const double es = h->es;
-    const double bytes = epi == EPI_SLAB ? ((double)g.K * g.M + (double)g.K * g.N) * es + (double)g.splits * g.M * g.N * 4.0
-                                         : ((double)g.nbatch * g.M * (g.K + g.N) + (double)g.K * g.N) * es;
-    prof_done(h, kname, algo_flops, bytes);
+    prof_done(h, kname, algo_flops, algo_bytes);
     CHK(r);
     return 0;
 }
+// activations [rows][K] in, [rows][N] out (element size es), the weight matrix once
+double dense_bytes(const mrgan_handle* h, double rows, const Dense& L) { return (rows * ((double)L.K + L.N) + (double)L.K * L.N) * h->es; }
+// weight gradient: both activation operands once, the fp32 gradient once
+double dw_bytes(const mrgan_handle* h, double rows, const Dense& L) { return rows * ((double)L.K + L.N) * h->es + (double)L.K * L.N * 4.0; }
 
 Epi base_epi(mrgan_handle* h) {
     Epi e;
@@ -507,7 +510,7 @@ int dense_fwd(mrgan_handle* h, const Dense& L, const void* x, int rows, int nb, 
     g.e.sigma = sigma; g.e.site = site; g.e.seg0 = seg0; g.e.seg_step = seg_step; g.e.iter_step = iter_step;
     g.e.mask = mask; g.e.mask_bs = (long)(h->S / 32) * ldm * 2; g.e.ldm = ldm;
     g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Np;
-    return run_gemm(h, EPI_FWD, g, 2.0 * rows * nb * L.K * L.N, s);
+    return run_gemm(h, EPI_FWD, g, 2.0 * rows * nb * L.K * L.N, dense_bytes(h, (double)rows * nb, L), s);
 }
 
 // dX = (dY W^T) * act'(prev): dY [nb][S][Np] -> out [nb][S][Kp]
@@ -526,7 +529,7 @@ int dense_dx(mrgan_handle* h, const Dense& L, const void* dy, int rows, int nb, 
     g.e.h = hprev; g.e.h_bs = (long)h->S * L.Kp; g.e.ldh = L.Kp;
     g.e.cs_mode = cs_mode; g.e.cs1 = cs1; g.e.cs2 = cs2; g.e.ldcs = L.Kp;
     g.e.bn_mu = h->bn_mu; g.e.bn_rstd = h->bn_rstd;
-    return run_gemm(h, EPI_DX, g, 2.0 * rows * nb * L.K * L.N, s);
+    return run_gemm(h, EPI_DX, g, 2.0 * rows * nb * L.K * L.N, dense_bytes(h, (double)rows * nb, L), s);
 }
 
 // dW slabs = X^T dY.  The nseg segments ([nseg][S] rows, `rows` valid in each) form ONE virtual reduction
@@ -563,12 +566,12 @@ int dense_dw_all(mrgan_handle* h, const DwJob* jobs, int n, int rows, int nseg, 
         prof_arm(h);
         const int r = launch_gemm_bf16_dw_group(gs, n, s, &kname, fold);
         double bytes = 0.0;
-        for (int i = 0; i < n; ++i) bytes += ((double)gs[i].K * gs[i].M + (double)gs[i].K * gs[i].N) * 2.0 + (double)gs[i].splits * gs[i].M * gs[i].N * 4.0;
+        for (int i = 0; i < n; ++i) bytes += dw_bytes(h, (double)rows * nseg, *jobs[i].L);
         prof_done(h, kname, total, bytes);
         if (r < 0) return fail(r, "grouped weight-gradient launch failed");
         if (r == 0) return 0;
     }
-    for (int i = 0; i < n; ++i) CHK(run_gemm(h, EPI_SLAB, gs[i], fl[i], s));
+    for (int i = 0; i < n; ++i) CHK(run_gemm(h, EPI_SLAB, gs[i], fl[i], dw_bytes(h, (double)rows * nseg, *jobs[i].L), s));
     if (fold) PROF("reduce_partials_kernel", launch_reduce_partials(fold->src, fold->nsrc, fold->stride, fold->n, fold->ngroups, fold->dst, s));
     return 0;
 }
@@ -889,10 +892,17 @@ int run_chain(mrgan_handle* h, const ChainArgs& c0, double flops, hipStream_t s)
                         tot[2] / nb / 1e3, tot[3] / nb / 1e3, tot[4] / nb / 1e3, tot[5] / nb / 1e3, tot[6] / nb / 1e3, tot[7] / nb / 1e3);
     }
 #endif
-    double bytes = 0.0;                    // first A image + every product's weights and stored output (bf16)
-    if (c.a_kind == CH_A_GLOBAL) bytes += (double)c.rows * c.nseg * c.a_cols * 2.0;
-    for (int i = 0; i < c.nops; ++i)
-        if (c.op[i].kind == CH_OP_GEMM) bytes += ((double)c.op[i].K * c.op[i].N + (double)c.rows * c.nseg * c.op[i].N) * 2.0;
+    // algorithmic bytes (logical widths, bf16): the first A image, every product's weights and stored output
+    double bytes = 0.0;
+    const double nrows = (double)c.rows * c.nseg;
+    const bool has_fwd = c.variant != CH_V_GBWD, has_dx = c.variant != CH_V_GFWD;
+    if (has_fwd) bytes += nrows * h->d[2].K * 2.0;
+    else bytes += nrows * h->F * 2.0;                                  // the stored features whose sign is the relu mask
+    for (int l = 2; l < 5; ++l) {
+        const double w = (double)h->d[l].K * h->d[l].N * 2.0;
+        if (has_fwd) bytes += w + nrows * h->d[l].N * 2.0;
+        if (has_dx) bytes += w + nrows * h->d[l].K * 2.0;
+    }
     static const char* names[3] = {"chain_kernel<0>", "chain_kernel<1>", "chain_kernel<2>"};     // as rocprofv3 prints them
     prof_done(h, names[c.variant], flops, bytes);
     CHK(r);
@@ -1536,8 +1546,9 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
         const int cur0 = h->cur;
         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         r = both();
+        graph = nullptr;
         hipError_t e = hipStreamEndCapture(s, &graph);
-        if (r) return r;
+        if (r) { if (graph) hipGraphDestroy(graph); return r; }       // a launch failed during capture: drop the partial graph
         if (e != hipSuccess) return fail(-10, "hipStreamEndCapture: %s", hipGetErrorString(e));
         e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);

@@ -318,11 +318,11 @@ int launch_kc(const GemmArgs& g, hipStream_t s) {
     constexpr int OUT = BM * BNT * 2 + 4 * WM * BNT * 4;
     constexpr int LDS = (NS * STAGE > OUT ? NS * STAGE : OUT) + ((EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU) ? BM * BNT * 2 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
+    static DeviceOnce attr;
     auto kern = gemm_bf16_kc_kernel<EPI, BM, BNT, WM, WN, NS, VAR, PIPE>;
-    if (!attr_done) {
+    if (attr.first()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
-        attr_done = true;
+        attr.mark();
     }
     // persistent blocks: at most as many as can be co-resident (LDS-limited) on the 256 CUs
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch;
@@ -485,11 +485,11 @@ int launch_ks_fast(const GemmArgs& g, hipStream_t s) {
     static const std::string name = "gemm_bf16_ks_fast_kernel<" + std::to_string(NS) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ">";
     g_last_kernel = name.c_str();
     constexpr int STAGE = 2 * 64 * 256;
-    static bool attr_done = false;
+    static DeviceOnce attr;
     auto kern = gemm_bf16_ks_fast_kernel<NS, WM, WN>;
-    if (!attr_done) {
+    if (attr.first()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE) != hipSuccess) return -2;
-        attr_done = true;
+        attr.mark();
     }
     dim3 grid(ceil_div(g.N, 128) * ceil_div(g.M, 128) * g.splits);
     MRGAN_LAUNCH(kern, grid, dim3(64 * WM * WN), NS * STAGE, s, g);
@@ -691,20 +691,20 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
     // TUNE_BIT_KS_W8 selects the 8-wave / 3-stage blocks (one per CU) again.
     constexpr int STAGE = 2 * 64 * 256;
     const int w8 = gs[0].e.tune_bits & TUNE_BIT_KS_W8;
-    static bool attr_done8 = false, attr_done = false;
+    static DeviceOnce attr8, attr4;
     if (w8) {
         auto kern = gemm_bf16_ks_group_kernel<3, 2, 4>;
-        if (!attr_done8) {
+        if (attr8.first()) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE) != hipSuccess) return -2;
-            attr_done8 = true;
+            attr8.mark();
         }
         MRGAN_LAUNCH(kern, dim3(total), dim3(512), 3 * STAGE, s, grp);
         if (kname) *kname = "gemm_bf16_ks_group_kernel<3, 2, 4>";
     } else {
         auto kern = gemm_bf16_ks_group_kernel<2, 2, 2>;
-        if (!attr_done) {
+        if (attr4.first()) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) return -2;
-            attr_done = true;
+            attr4.mark();
         }
         MRGAN_LAUNCH(kern, dim3(total), dim3(256), 2 * STAGE, s, grp);
         if (kname) *kname = "gemm_bf16_ks_group_kernel<2, 2, 2>";

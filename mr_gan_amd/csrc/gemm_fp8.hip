@@ -328,10 +328,10 @@ int launch_fp8_cfg(const GemmArgs& g, hipStream_t s) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BNT) * g.nbatch * (EPI == EPI_SLAB ? g.splits : 1);
     dim3 grid(std::min(tiles, 256 * std::max(1, (160 * 1024) / LDS)));
     auto kern = gemm_fp8_kc_kernel<EPI, BM, BNT, WM, WN, VAR, OUT8>;
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.first()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -2;
-        attr = true;
+        attr.mark();
     }
     MRGAN_LAUNCH(kern, grid, dim3(64 * WM * WN), LDS, s, g);
     return 0;

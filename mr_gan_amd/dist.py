@@ -153,6 +153,10 @@ class DataParallel(object):
         # the device (the engine could not know a host-supplied z in advance).
         hint = getattr(self.backend, "pair_hint", None)
         paired = hint is not None and not getattr(gargs, "z", None)
+        # fp8: settle the D sub-step's scales BEFORE the hint is given.  A hint is good for one D sub-step, and the first
+        # dry pass would consume it: the real pass would then run unpaired while gen_step below still skipped its BatchNorm
+        # exchange (stats_done), i.e. normalised with unreduced statistics in its first calibration pass.
+        self._calibrate(0, lambda: self._disc_fwd_bwd(dargs))
         if paired:
             hint(True)
         self.disc_step(dargs)

@@ -123,7 +123,7 @@ class MRGAN(object):
 
     # ---- Keras-shaped API ---------------------------------------------------------------------------------------
     def _fit(self, x_labeled, y_labeled, x_unlabeled, epochs=100, batch_size=None, verbose=0, validation_data=None,
-            x_unlabeled_pool=None, rng=None):
+            x_unlabeled_pool=None, rng=None, z_source='device'):
         """The epoch loop of mr_gan.py:183-228.
 
         x_labeled / y_labeled: the class-sorted labeled subset (mr_gan.py:102-103);
@@ -131,7 +131,10 @@ class MRGAN(object):
         x_unlabeled_pool: table-6 restricted pool (mr_gan.py:197-202), else None.
         The matrices are uploaded once and stay resident in HBM; per epoch only the permutation index
         streams (mr_gan.py:189-195) go to the device, and the per-batch scalars are accumulated on the
-        device and read back once per epoch."""
+        device and read back once per epoch.
+        z_source: 'device' draws the generator input on the GPU (the engine's counter-based generator, DESIGN.md section 4);
+        'host' draws it as the reference does, np.random.normal(0, 1, [B, noise]) twice per iteration (mr_gan.py:206, :212),
+        from `rng`, and uploads one epoch's worth at a time."""
         if batch_size is not None and batch_size != self.batch_size:
             raise ValueError("batch_size is fixed at construction (%d)" % self.batch_size)
         rng = rng or np.random.RandomState(self.seed ^ 0x5bd1e995)
@@ -160,8 +163,14 @@ class MRGAN(object):
             lab_stream = self._dev(yl[inds], torch.int32)
             idx_unl = self._dev(unl[0], torch.int32)
             idx_unl2 = self._dev(unl[1], torch.int32)
-            dargs = E.Engine.disc_args(xl, lab_stream, unl_src, None, idx_lab, idx_unl, stream_mode=1)
-            gargs = E.Engine.gen_args(unl_src, None, idx_unl2, stream_mode=1)
+            z1 = z2 = None
+            if z_source == 'host':
+                zz = rng.normal(0.0, 1.0, size=(nb, 2, B, self.cfg.noise_size)).astype(np.float32)       # :206 then :212, per iteration
+                z1, z2 = self._dev(zz[:, 0].reshape(nb * B, -1)), self._dev(zz[:, 1].reshape(nb * B, -1))
+            elif z_source != 'device':
+                raise ValueError("z_source must be 'device' or 'host'")
+            dargs = E.Engine.disc_args(xl, lab_stream, unl_src, z1, idx_lab, idx_unl, stream_mode=1)
+            gargs = E.Engine.gen_args(unl_src, z2, idx_unl2, stream_mode=1)
             self.engine.set_iterations(self.iterations, 0)
             for _ in range(nb):                                    # mr_gan.py:204-213
                 self.engine.train_pair(dargs, gargs)

@@ -122,17 +122,31 @@ def dataset(modalities=0, forcetempTime=4, contactmicTime=0.2, leaveObjectOut=Fa
     return X, y
 
 
-def _kfold(X, y, run, verbose):
-    from sklearn.model_selection import StratifiedKFold
-    errors = []
-    skf = StratifiedKFold(n_splits=6, shuffle=True)              # mr_gan.py:255
-    for trainIdx, testIdx in skf.split(X, y):
-        errors.append(run([X[trainIdx], X[testIdx], y[trainIdx], y[testIdx]]))
-        print('Test error:', errors[-1], 'Test accuracy:', 1.0 - errors[-1])
-        sys.stdout.flush()
-    print('Average error:', np.mean(errors), 'Average accuracy:', np.mean(1.0 - np.array(errors)))
-    sys.stdout.flush()
-    return errors
+class InProcessRuns(object):
+    """The scheduler's interface (put_dataset / run) executed in this process, one training after the other: what
+    `--gpus 0` (the default, the reference's own behaviour) uses, so that every table has ONE set of job builders."""
+
+    def __init__(self, mr_gan_fn):
+        self.fn, self.datasets = mr_gan_fn, {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def put_dataset(self, X, y):
+        self.datasets[len(self.datasets)] = (X, y)
+        return len(self.datasets) - 1
+
+    def run(self, jobs):
+        out = []
+        for job in jobs:
+            kw = {k: v for k, v in job.items() if k not in ('dataset', 'train_idx', 'test_idx')}
+            X, y = self.datasets[job['dataset']]
+            tr, te = job['train_idx'], job['test_idx']
+            out.append(self.fn(None, None, trainTestSets=[X[tr], X[te], y[tr], y[te]], **kw))
+        return out
 
 
 def _kfold_jobs(X, y, key, **job_kw):
@@ -178,13 +192,17 @@ def _table3_scheduled(sched, dataset_fn, kw):
         print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
         objects = dataset_fn(modalities=modality, leaveObjectOut=True)
         names = list(objects.keys())
+        # the objects' rows once, in the reference's order (mr_gan.py:277-278 chains them in dict order): a job is two index
+        # vectors into that matrix instead of its own copy of ~7000 training rows
+        Xall = np.array(list(itertools.chain.from_iterable(objects[n]['x'] for n in names)))
+        yall = np.array(list(itertools.chain.from_iterable(objects[n]['y'] for n in names)))
+        owner = np.concatenate([np.full(len(objects[n]['y']), i) for i, n in enumerate(names)])
+        key = sched.put_dataset(Xall, yall)
         jobs = []
         for percent in percents:
-            for objName in names:
-                Xtest, ytest = np.array(objects[objName]['x']), np.array(objects[objName]['y'])
-                Xtrain = np.array(list(itertools.chain.from_iterable([d['x'] for n, d in objects.items() if n != objName])))
-                ytrain = np.array(list(itertools.chain.from_iterable([d['y'] for n, d in objects.items() if n != objName])))
-                jobs.append(dict(trainTestSets=[Xtrain, Xtest, ytrain, ytest], percentlabeled=percent, **kw))
+            for i in range(len(names)):
+                jobs.append(dict(dataset=key, train_idx=np.flatnonzero(owner != i), test_idx=np.flatnonzero(owner == i),
+                                 percentlabeled=percent, **kw))
         errors = sched.run(jobs)
         for i, percent in enumerate(percents):
             print('-' * 15, 'Percentage of training data labeled: %d%%' % percent, '-' * 15)
@@ -242,80 +260,22 @@ def main(argv=None, dataset_fn=dataset, mr_gan_fn=mr_gan, scheduler_factory=None
                         help='run-level scheduling: dispatch the independent trainings of tables 1 / 3 / 5 / 6 over this many GPUs (0 = in-process, sequential)')
     parser.add_argument('--jobs-per-gpu', type=int, default=1, help='concurrent trainings per GPU with --gpus')
     args = parser.parse_args(argv)
-    kw = dict(epochs=args.epochs, dtype=args.dtype, verbose=args.verbose)
-
-    if args.gpus > 0:                                              # same tables, trainings dispatched by the scheduler
+    kw = dict(epochs=args.epochs, dtype=args.dtype)
+    if args.gpus > 0:                                              # the independent trainings dispatched over worker processes
         from mr_gan_amd.scheduler import RunScheduler
-        skw = dict(epochs=args.epochs, dtype=args.dtype)
-        with (scheduler_factory or RunScheduler)(gpus=args.gpus, jobs_per_gpu=args.jobs_per_gpu) as sched:
-            if '1' in args.tables:
-                _table1_scheduled(sched, dataset_fn, skw)
-            if '3' in args.tables:
-                _table3_scheduled(sched, dataset_fn, skw)
-            if '5' in args.tables:
-                _table5_scheduled(sched, dataset_fn, skw)
-            if '6' in args.tables:
-                _table6_scheduled(sched, dataset_fn, skw)
-        return
-    if '1' in args.tables:                                         # mr_gan.py:244-261
-        print('\n', '-' * 25, 'Testing various amounts of labeled training data', '-' * 25)
-        print('-' * 100)
-        for modality in range(len(MODALITIES)):
-            print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
-            X, y = dataset_fn(modalities=modality)
-            for percent in [1, 2, 4, 8, 16, 50, 100]:
-                print('-' * 15, 'Percentage of training data labeled: %d%%' % percent, '-' * 15)
-                _kfold(X, y, lambda sets: mr_gan_fn(None, None, percentlabeled=percent, trainTestSets=sets, **kw), args.verbose)
-
-    if '3' in args.tables:                                         # mr_gan.py:263-283
-        print('\n', '-' * 25, 'Testing generalization with leave-one-object-out validation', '-' * 25)
-        print('-' * 100)
-        for modality in [2, 5]:
-            print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
-            objects = dataset_fn(modalities=modality, leaveObjectOut=True)
-            for percent in [1, 4, 16, 50, 100]:
-                print('-' * 15, 'Percentage of training data labeled: %d%%' % percent, '-' * 15)
-                errors = []
-                for objName, objData in objects.items():
-                    Xtest = np.array(objData['x'])
-                    ytest = np.array(objData['y'])
-                    Xtrain = np.array(list(itertools.chain.from_iterable([d['x'] for n, d in objects.items() if n != objName])))
-                    ytrain = np.array(list(itertools.chain.from_iterable([d['y'] for n, d in objects.items() if n != objName])))
-                    errors.append(mr_gan_fn(None, None, percentlabeled=percent, trainTestSets=[Xtrain, Xtest, ytrain, ytest], **kw))
-                    print(objName, 'Test error:', errors[-1], 'Test accuracy:', 1.0 - errors[-1])
-                    sys.stdout.flush()
-                print('Average leave-one-object-out error:', np.mean(errors), 'Average accuracy:', np.mean(1.0 - np.array(errors)))
-                sys.stdout.flush()
-
-    if '5' in args.tables:                                         # mr_gan.py:285-318
-        print('\n', '-' * 25, 'Testing various lengths of contact time in training data', '-' * 25)
-        print('-' * 100)
-        for modality in range(3):
-            print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
-            for ftTime in [4, 3, 2, 1, 0.5, 0.2, 0.1]:
-                print('-' * 15, 'Length of training data: %.1fs' % ftTime, '-' * 15)
-                X, y = dataset_fn(modalities=modality, forcetempTime=ftTime)
-                _kfold(X, y, lambda sets: mr_gan_fn(None, None, percentlabeled=100, trainTestSets=sets, **kw), args.verbose)
-        print('\n', '-' * 25, 'Testing various lengths of contact time in training data', '-' * 25)
-        print('-' * 100)
-        print('-' * 25, MODALITIES[3], 'modality', '-' * 25)
-        for cTime in [1, 0.7, 0.5, 0.3, 0.2, 0.1, 0.05]:
-            print('-' * 15, 'Length of training data: %.1fs' % cTime, '-' * 15)
-            X, y = dataset_fn(modalities=3, contactmicTime=cTime)
-            _kfold(X, y, lambda sets: mr_gan_fn(None, None, percentlabeled=100, trainTestSets=sets, **kw), args.verbose)
-
-    if '6' in args.tables:                                         # mr_gan.py:320-341
-        print('\n', '-' * 25, 'Testing performance as quantity of unlabeled data increases', '-' * 25)
-        print('-' * 100)
-        for modality in [2, 5]:
-            print('-' * 25, MODALITIES[modality], 'modality', '-' * 25)
-            X, y = dataset_fn(modalities=modality)
-            for percentlabeled in [4]:
-                print('-' * 15, 'Percentage of training data labeled: %d%%' % percentlabeled, '-' * 15)
-                for percentunlabeled in [0, 4, 8, 16, 32, 64, 100 - percentlabeled]:
-                    print('-' * 15, 'Percentage of training data unlabeled: %d%%' % percentunlabeled, '-' * 15)
-                    _kfold(X, y, lambda sets: mr_gan_fn(None, None, percentlabeled=percentlabeled,
-                                                        percentunlabeled=percentunlabeled, trainTestSets=sets, **kw), args.verbose)
+        runs = (scheduler_factory or RunScheduler)(gpus=args.gpus, jobs_per_gpu=args.jobs_per_gpu)
+    else:                                                          # the reference's behaviour: one after the other, here
+        runs = InProcessRuns(mr_gan_fn)
+        kw['verbose'] = args.verbose
+    with runs as sched:
+        if '1' in args.tables:                                     # mr_gan.py:244-261
+            _table1_scheduled(sched, dataset_fn, kw)
+        if '3' in args.tables:                                     # mr_gan.py:263-283
+            _table3_scheduled(sched, dataset_fn, kw)
+        if '5' in args.tables:                                     # mr_gan.py:285-318
+            _table5_scheduled(sched, dataset_fn, kw)
+        if '6' in args.tables:                                     # mr_gan.py:320-341
+            _table6_scheduled(sched, dataset_fn, kw)
 
 
 if __name__ == '__main__':

@@ -15,6 +15,9 @@ from mr_gan_amd.data import MATERIALS, select_labeled, standard_scale
 from mr_gan_amd.mr_gan import MODALITIES, dataset
 
 
+SVC_GAMMA = 'auto'
+
+
 def mr_svm(X, y, percentlabeled=50, trainTestSets=None, verbose=False, seed=None):
     from sklearn.model_selection import train_test_split
     from sklearn.svm import SVC
@@ -34,7 +37,10 @@ def mr_svm(X, y, percentlabeled=50, trainTestSets=None, verbose=False, seed=None
     x_labeled, y_labeled, _ = select_labeled(X_train, y_train, num_labeled_examples)
     if verbose:
         print('x_labeled:', np.shape(x_labeled), 'y_labeled:', np.shape(y_labeled))
-    svm = SVC(kernel='rbf', C=1.0)                                 # mr_svm.py:106
+    # mr_svm.py:106 is SVC(kernel='rbf', C=1.0) under the scikit-learn of 2017 (Keras 2.0.9 era, README.md:43-48), whose default
+    # kernel width was gamma='auto' = 1 / n_features.  scikit-learn >= 0.22 defaults to 'scale' (1 / (n_features * X.var())),
+    # which differs on the small standardised labeled subset: pass the reference's value explicitly.
+    svm = SVC(kernel='rbf', C=1.0, gamma=SVC_GAMMA)
     svm.fit(x_labeled, y_labeled)
     testerror = 1.0 - svm.score(X_test, y_test)                    # mr_svm.py:110
     if verbose:

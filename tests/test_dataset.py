@@ -94,7 +94,11 @@ def test_svm_baseline_and_its_tables(capsys):
     a, ya = shuffle(a, sets[2], random_state=np.random.RandomState(3))
     xl = np.concatenate([a[ya == j][:20] for j in range(6)])
     yl = np.concatenate([[j] * 20 for j in range(6)])
-    want = 1.0 - SVC(kernel='rbf', C=1.0).fit(xl, yl).score(b, sets[3])
+    # gamma: the reference relies on the scikit-learn default of its time, 'auto' = 1 / n_features (mr_svm.py:106; the
+    # installed scikit-learn would pick 'scale', another kernel width on this 120-row subset)
+    import mr_gan_amd.mr_svm as S
+    assert S.SVC_GAMMA == 'auto'
+    want = 1.0 - SVC(kernel='rbf', C=1.0, gamma=1.0 / xl.shape[1]).fit(xl, yl).score(b, sets[3])
     assert got == want and got < 0.5
 
     rs = np.random.RandomState(0)

@@ -272,3 +272,81 @@ def test_dp_flags():
     from mr_gan_amd.dist import dp_flags
     assert dp_flags(True) == E.FLAG_FLAT_GRADS | E.FLAG_SYNC_STATS
     assert dp_flags(False) == E.FLAG_FLAT_GRADS
+
+
+class _PairingStub(object):
+    """Records the phase / exchange sequence dist.DataParallel issues, with the engine's pairing and fp8-calibration state
+    machine restated from csrc/engine.hip: a pair hint is good for ONE D sub-step (D_MAIN hands it over as `gen_ready` and clears
+    it; any later D_MAIN without a hint resets gen_ready); G_GEN re-runs the generator head -- and so rewrites the BatchNorm
+    sums of its segment -- unless gen_ready is set.  `stale` counts generator tails that normalised with sums no exchange had
+    completed."""
+
+    def __init__(self, fp8):
+        from mr_gan_amd import engine as E
+        self.E = E
+        self.cal = [not fp8, not fp8]
+        self.pair_gen = self.gen_ready = 0
+        self.reduced = {0: True, 1: True}          # BatchNorm sums of generator segment s have been all-reduced
+        self.stale = 0
+        self.log = []
+
+    def pair_hint(self, on=True):
+        self.pair_gen = 1 if on else 0
+
+    def fp8_calibration(self, kind, action):
+        E = self.E.Engine
+        if action == E.FP8_CAL_QUERY:
+            return 1 if self.cal[kind] else 0
+        if action == E.FP8_CAL_DONE:
+            self.cal[kind] = True
+        return 0
+
+    def exchanged(self, which):
+        self.log.append(('allreduce', which))
+        if which == self.E.REGION_BN_STATS:
+            self.reduced = {0: True, 1: True}
+
+    def disc_phase(self, args, phase):
+        E = self.E
+        self.log.append(('D', phase))
+        if phase == E.D_GEN:
+            self.reduced[0] = False
+            if self.pair_gen:
+                self.reduced[1] = False
+        elif phase == E.D_MAIN:
+            self.stale += 0 if self.reduced[0] and (not self.pair_gen or self.reduced[1]) else 1
+            self.gen_ready, self.pair_gen = self.pair_gen, 0
+
+    def gen_phase(self, args, phase):
+        E = self.E
+        self.log.append(('G', phase))
+        if phase == E.G_GEN:
+            self.view = 1 if self.gen_ready else 0
+            if not self.gen_ready:
+                self.reduced[0] = False
+        elif phase == E.G_FEAT:
+            self.stale += 0 if self.reduced[self.view] else 1
+            self.gen_ready = 0
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_train_pair_never_normalises_with_unreduced_statistics(fp8):
+    """exact data parallelism + train_pair (+ fp8 calibration): every generator tail runs behind a completed BatchNorm-sum
+    exchange.  Regression test for the first fp8 pair, where the D sub-step's first dry pass used to consume the pair hint
+    and the G sub-step's first dry pass then skipped its exchange although it had just rewritten the sums."""
+    from mr_gan_amd import engine as E
+    from mr_gan_amd.dist import DataParallel
+
+    class Recording(DataParallel):
+        def _allreduce(self, which):
+            self.backend.exchanged(which)
+
+    stub = _PairingStub(fp8)
+    dp = Recording(stub, exact=True)
+    for _ in range(3):
+        dp.train_pair(object(), object())
+    assert stub.stale == 0, stub.log
+    # steady state: one BatchNorm exchange per pair (both segments travel in the D sub-step's)
+    tail = stub.log[-13:]
+    assert sum(1 for ev in tail if ev == ('allreduce', E.REGION_BN_STATS)) == 1, tail
+    assert stub.cal == [True, True]

@@ -398,7 +398,7 @@ def _grad_parity(D, B, dtype, quantize, tol, tol_loss, d_hidden=None, g_hidden=N
     mir = O.MRGANMirror(case.g0, case.d0, quantize=quantize)
     orc = O.MRGANOracle(case.g0, case.d0)
     (ll, lu, err), gd_m, _ = mir.disc_grads(**case.disc_inputs(0, 0))
-    _, gd_o, _ = orc.disc_grads(**case.disc_inputs(0, 0))
+    (ll_o, lu_o, _), gd_o, _ = orc.disc_grads(**case.disc_inputs(0, 0))
     eng = _engine(D, B, dtype, flags=E.FLAG_FLAT_GRADS, **kw)
     _load(eng, case)
     if eval_first:
@@ -420,7 +420,11 @@ def _grad_parity(D, B, dtype, quantize, tol, tol_loss, d_hidden=None, g_hidden=N
 
     check("dD", eng.get_slot(E.NET_D, 2), gd_m, gd_o, loose[0])
     out = eng.disc_step(da, E.D_ADAM, E.D_ADAM)
-    np.testing.assert_allclose(out[:2], (ll, lu), rtol=tol_loss, atol=tol_loss * 0.1)
+    # losses: the same rule as the gradients -- within tol_loss of the mirror, or within `frac` of what the storage format itself
+    # does to the loss (mirror vs fp64), whichever is larger (reductions of length 4096 in fp8: 2.0e-3 against a mirror that is
+    # itself 1 % from fp64)
+    for got_l, m_l, o_l in zip(out[:2], (ll, lu), (ll_o, lu_o)):
+        np.testing.assert_allclose(got_l, m_l, rtol=max(tol_loss, frac * abs(m_l - o_l) / max(abs(o_l), 1e-12)), atol=tol_loss * 0.1)
     assert abs(out[2] - err) <= ((4.01 if quantize == 'fp8' else 1.01) / B if quantize else 1e-6)      # an argmax or two may flip
     # the G sub-step sees the D network AFTER its update: give engine, mirror and oracle the same updated weights
     mir.adam.apply(mir.d, gd_m, 'd')
@@ -446,6 +450,8 @@ def _grad_parity(D, B, dtype, quantize, tol, tol_loss, d_hidden=None, g_hidden=N
                                  (400, 256),      # reference-sized input, several row tiles
                                  (3632, 512),     # all three modalities fused, one rank's shard of batch 4096
                                  (2432, 1024),    # config 4: contact-mic log-mel only
+                                 (800, 1024),     # config 4: force only
+                                 (400, 1024),     # config 4: temperature only
                                  (512, 4096)])    # config 2: the bench workload at full size
 def test_bf16_gradients_match_bf16_mirror(D, B):
     _grad_parity(D, B, 1, 'bf16', tol=3e-3, tol_loss=5e-4)
@@ -494,7 +500,10 @@ def test_wide_stack_bf16_matches_bf16_mirror():
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("D,B,hidden", [(400, 256, None),          # reference widths (padded to multiples of 128), 128x128 blocks
                                         (200, 50, None),           # ragged batch: the transposed copies keep zero padding rows
-                                        (512, 1024, 2048)])        # wide stack, K = 2048 reductions
+                                        (512, 1024, 2048),         # wide stack, K = 2048 reductions
+                                        (512, 1024, 4096)])        # BASELINE configs[4] at one rank's share (8192 / 8 rows): hidden
+                                                                   # 4096 x 5, generator 4096 x 2, default tile selection, the
+                                                                   # split first-layer weight gradient and the calibration as shipped
 def test_fp8_gradients_match_fp8_mirror(D, B, hidden):
     """One D and one G sub-step with MRGAN_FP8 (gemm_fp8.hip: e4m3 activations / weights, e5m2 gradients, delayed power-of-two
     scales settled by the dry passes of the first sub-step) against MRGANMirror(quantize='fp8'), which rounds to fp8 exactly
@@ -750,6 +759,72 @@ def test_accuracy_parity_on_mreo_surrogate():
         # Measured: +0.0 .. +0.5 % (50 labeled rows per class), +0.1 .. +0.2 % (500).
         assert abs(last5[(n_lab, 'fp8')] - float(np.mean(a))) <= 0.01 + 1e-9, (n_lab, "fp8 last-10 mean", last5[(n_lab, 'fp8')], a)
         assert err[(n_lab, 'fp8')] < 0.05 and abs(err[(n_lab, 'fp8')] - float(np.mean(e))) <= 0.015 + 1e-9, (n_lab, "fp8 final", err[(n_lab, 'fp8')], e)
+
+
+def test_six_fold_mean_accuracy_parity_on_mreo_surrogate():
+    """The quantity the reference reports (mr_gan.py:255-260): the mean over SIX stratified folds of the final whole-test-set
+    error (mr_gan.py:230), on the MREO-shaped surrogate at the real size (N 7200, D 1200, batch 50, 50 labeled rows per class
+    = BASELINE configs[0]), held to north_star's +-0.5 % absolute between
+        (a) the HIP engine in fp32, (b) the HIP engine in bf16, (c) the CPU oracle (float32 numpy, six worker processes),
+    every fold from the same initial weights, index streams and z / GaussianNoise streams on all three paths.  Averaging over
+    the folds removes most of the +-0.3 % single-trajectory noise that test_accuracy_parity_on_mreo_surrogate (one fold; the
+    labelled loose check, 1 % on a single final evaluation) comments on.
+    (d) the bf16 engine once more with z drawn on the HOST by np.random.normal, as mr_gan.py:206 / :212 do, instead of the
+    engine's Irwin-Hall(32) generator (a documented deviation from N(0, 1)): the six-fold mean must not
+    move by more than the same 0.5 % -- evidence that the generator's distribution is harmless.  (The GaussianNoise layers keep
+    the device generator on every path: they are fused into the product epilogues.)
+    20 epochs instead of the reference's 100 keep the six numpy loops at ~2 min of wall time."""
+    from sklearn.model_selection import StratifiedKFold
+    from mr_gan_amd import MRGAN, select_labeled, standard_scale, synthetic_mreo
+    from tests.helpers import oracle_fit_job
+    import multiprocessing as mp
+    import os
+    epochs, seed, n_lab = 20, 4321, 50
+    X, y, _ = synthetic_mreo(sep=0.5)
+    folds = []
+    for k, (tr, te) in enumerate(StratifiedKFold(n_splits=6, shuffle=True, random_state=0).split(X, y)):
+        Xtr, Xte = standard_scale(X[tr], X[te])
+        ytr, yte = y[tr], y[te]
+        perm = np.random.RandomState(100 + k).permutation(len(ytr))          # mr_gan.py:101
+        Xtr, ytr = Xtr[perm], ytr[perm]
+        xl, yl, _ = select_labeled(Xtr, ytr, n_lab)
+        folds.append((Xtr, Xte, yte, xl, yl))
+    m0 = MRGAN(X.shape[1], batch_size=50, dtype='float32', seed=seed)
+    g0, d0 = m0.get_weights('generator'), m0.get_weights('discriminator')
+    m0.engine.close()
+    old = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS")}
+    os.environ["OPENBLAS_NUM_THREADS"] = os.environ["OMP_NUM_THREADS"] = "2"          # 6 workers x 2 BLAS threads
+    pool = mp.get_context("spawn").Pool(6)
+    err = {}
+    try:
+        asyncs = [pool.apply_async(oracle_fit_job, (dict(g0=g0, d0=d0, x_labeled=xl, y_labeled=yl, x_train=Xtr, x_test=Xte, y_test=yte,
+                                                         batch=50, epochs=epochs, seed=seed + k, rng_seed=5 + k),))
+                  for k, (Xtr, Xte, yte, xl, yl) in enumerate(folds)]
+        for name, dt, zsrc in (('float32', 'float32', 'device'), ('bfloat16', 'bfloat16', 'device'), ('bfloat16_host_z', 'bfloat16', 'host')):
+            for k, (Xtr, Xte, yte, xl, yl) in enumerate(folds):
+                m = MRGAN(X.shape[1], batch_size=50, dtype=dt, seed=seed + k, init_weights=False)
+                m.set_weights(g0, 'generator')
+                m.set_weights(d0, 'discriminator')
+                m.fit(xl, yl, Xtr, epochs=epochs, rng=np.random.RandomState(5 + k), z_source=zsrc)
+                err[(name, k)] = m.evaluate(Xte, yte)
+                m.engine.close()
+        for k, a in enumerate(asyncs):
+            err[('oracle', k)] = a.get(timeout=800)[0]
+    finally:
+        pool.terminate()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    names = ('float32', 'bfloat16', 'oracle', 'bfloat16_host_z')
+    mean = {n: float(np.mean([err[(n, k)] for k in range(6)])) for n in names}
+    print("\nfinal whole-test-set error per fold after %d epochs, and the six-fold mean\n  " % epochs +
+          "\n  ".join("%-16s %s  mean %.4f" % (n, " ".join("%.4f" % err[(n, k)] for k in range(6)), mean[n]) for n in names))
+    assert max(mean.values()) < 0.05, mean                                       # everybody learned the task
+    three = [mean[n] for n in ('float32', 'bfloat16', 'oracle')]
+    assert max(three) - min(three) <= 0.005 + 1e-9, ("six-fold mean, +-0.5 %", mean)
+    assert abs(mean['bfloat16_host_z'] - mean['bfloat16']) <= 0.005 + 1e-9, ("host-drawn normal z vs the device generator", mean)
 
 
 def test_graph_replay_equals_eager():

@@ -172,5 +172,9 @@ def test_scheduled_tables_3_5_6_dispatch_every_training(capsys):
     assert 'm0_o0 Test error: 0.125 Test accuracy: 0.875' in out
     t6 = [j for j in f.jobs if j.get('percentunlabeled') is not None]
     assert sorted({j['percentunlabeled'] for j in t6}) == [0, 4, 8, 16, 32, 64, 96] and all(j['percentlabeled'] == 4 for j in t6)
-    loo = [j for j in f.jobs if 'trainTestSets' in j]
-    assert len(loo) == 180 and loo[0]['trainTestSets'][1].shape == (5, 4) and loo[0]['trainTestSets'][0].shape == (85, 4)
+    # leave-one-object-out jobs are index vectors into ONE shipped matrix (no per-job copy of the training rows): the held-out
+    # object's 5 rows against the 85 others, every object held out once per label fraction
+    loo = f.jobs[:180]
+    assert all('trainTestSets' not in j for j in f.jobs)
+    assert len(loo[0]['test_idx']) == 5 and len(loo[0]['train_idx']) == 85 and not set(loo[0]['test_idx']) & set(loo[0]['train_idx'])
+    assert sorted(int(j['test_idx'][0]) for j in loo[:18]) == list(range(0, 90, 5))
