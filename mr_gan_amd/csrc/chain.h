@@ -31,6 +31,8 @@ enum { CH_FWD_RELU = 0, CH_DX_RELU = 1 };
 enum { CH_A_GLOBAL = 0, CH_A_LDS = 1, CH_A_FMGRAD = 2 };
 // the three chains of a training step: op lists [F F F H X X X], [F F F], [X X X] (F forward, H loss head, X dX)
 enum { CH_V_DTAIL = 0, CH_V_GFWD = 1, CH_V_GBWD = 2 };
+// timing experiments (results are wrong): skip the loss head / the copies to HBM / the MFMAs / the weight stream / the epilogue math
+enum { CH_ABL_HEAD = 256, CH_ABL_COPY = 512, CH_ABL_MFMA = 1024, CH_ABL_STREAM = 2048, CH_ABL_EPI = 4096 };
 
 struct ChainOp {
     int kind;                          // CH_OP_*
@@ -61,6 +63,8 @@ struct ChainArgs {
     int seg0;                          // noise segment id of segment 0
     uint64_t seed; uint32_t row0; const DevState* st;
     unsigned long long* stamps;        // diagnostic build only (make STAMPS=1): [block][8] cycles per phase
+    int ablate;                        // timing experiments only (mrgan_debug_ablate): CH_ABL_* bits
+
 };
 
 int launch_chain(const ChainArgs& a, hipStream_t s);

@@ -863,6 +863,7 @@ ChainOp chain_dx_op(mrgan_handle* h, int l, int a_off, int o_off, bool bias_sums
 void chain_common(mrgan_handle* h, ChainArgs& c, int nseg) {
     c.rows = h->B; c.nseg = nseg; c.S = h->S; c.seg0 = 0;
     c.seed = h->cfg.seed; c.row0 = (uint32_t)(h->cfg.rank * h->B); c.st = h->state + h->cur;
+    c.ablate = h->ablate;
 }
 double chain_flops(const mrgan_handle* h, const ChainArgs& c, bool with_head) {
     double f = 0.0;
@@ -993,6 +994,9 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
             c.op[0] = chain_fwd_op(h, 2, CH_BUF0, CH_BUF1, false);
             c.op[1] = chain_fwd_op(h, 3, CH_BUF1, CH_BUF0, false);
             c.op[2] = chain_fwd_op(h, 4, CH_BUF0, CH_BUF1, false);
+            // the relu masks of D3 .. D5 never leave the launch's registers (their dX products follow in the same launch, and
+            // nothing else reads them in a D sub-step): no copies to HBM
+            for (int i = 0; i < 3; ++i) c.op[i].mask = nullptr;
             c.op[3].kind = CH_OP_HEAD;
             c.head = hd; c.head_f_off = CH_BUF1; c.head_o_off = CH_BUF0; c.head_scratch_off = CH_BUF0 + CH_BUF0_BYTES / 2;
             c.op[4] = chain_dx_op(h, 4, CH_BUF0, CH_BUF1, true);

@@ -88,155 +88,284 @@ __device__ __forceinline__ void copy_out(const char* img, __bf16* out, int ldo, 
     }
 }
 
+// Shared state of the weight-tile stream of one block (all wave-uniform)
+struct Stream {
+    BCursor pc; bool more; int gtile;
+    // The copy of a finished output image to HBM is DEFERRED to the end of the next pass's k-loop.  Stores count in vmcnt in issue
+    // order with the weight-tile DMAs: issued right behind the image barrier (round 2) they sat in front of the next tile's
+    // DMA, and the wait for that tile -- one k-tile of MFMAs later -- also waited for the stores' acknowledgement (~1 us per
+    // pass, measured by ablation).  At the end of a k-loop the only DMA in flight is OLDER than the stores (the next product's
+    // first tile), and the following wait comes a whole epilogue later.  The image is read-only until the product after next.
+    const char* cp_img; __bf16* cp_out; int cp_ldo, cp_col0, cp_ncols;
+};
+__device__ __forceinline__ void flush_copy(Stream& sm, int rows_valid, int t) {
+    if (sm.cp_img) copy_out(sm.cp_img, sm.cp_out, sm.cp_ldo, sm.cp_col0, sm.cp_ncols, rows_valid, t);
+    sm.cp_img = nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
-// loss head on the block's 64 rows (mr_gan.py:128, :146-149, :161): same arithmetic as head_kernel (aux_kernels.hip),
-// features read from the LDS image, dL/d(pre-activation of the feature layer) written as the next A image.
+// loss head on the block's 64 rows (mr_gan.py:128, :146-149, :161), on the matrix cores.
+// The three small products of the head -- logits = F W6, dL/d(pre5) = (dlogits W6^T) * relu', dW6 = F^T dlogits -- were scalar
+// fmaf loops (24 k cycles per block, 22 % of the launch for 0.1 % of its FLOPs).  They are MFMA products now, at fp32
+// accuracy: the features are exact bf16 values already, and every fp32 factor (W6, dlogits) enters as THREE bf16 addends
+// hi + mid + lo that reproduce it exactly (8 + 8 + 8 significant bits), so each bf16 x bf16 product is exact in the fp32
+// accumulator and only the summation order differs from head_kernel's fmaf chain (aux_kernels.hip).
+//   1. W6 -> LDS as [3 addends][class][feature] bf16 (the B operand of the logits product, k = feature contiguous)
+//   2. logits: every wave takes 32 of the features as its share of the reduction (2 k-steps x 2 row tiles x 3 addends), the
+//      eight partial [64][8] tiles meet in LDS
+//   3. wave 0, one lane per row: softmax / losses / closed-form dlogits, dlogits -> LDS as bf16 addends, row-major
+//      (A operand of 4) and class-major (A operand of 5)
+//   4. dL/d(pre5) for the wave's 32 feature columns: one 16-deep k-step (8 classes + 8 zeros) x 6 addend pairs, masked with
+//      the relu bits the D5 forward epilogue left in registers, written as the next product's A image (+ bias-gradient sums)
+//   5. dW6^T [class][feature] = dlogits^T F for the wave's 32 features: F enters through the transposing LDS read
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void chain_head(const ChainArgs& a, char* lds, int seg, int rb, int nrb, int row_blk, int rows_valid, int t) {
+__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)v;
+    float r = v - (float)hi;            // exact: the remainder of a round-to-nearest has at most 16 significant bits
+    mid = (__bf16)r;
+    r -= (float)mid;                    // exact: at most 8 significant bits remain
+    lo = (__bf16)r;
+}
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+// what the head reads from global memory, fetched in the kernel's prologue: inside the head each of these would be an exposed
+// L2 / HBM round trip with the whole block waiting at the next barrier (the labels even two dependent ones)
+struct HeadInputs { f32x4 w0, w1, bw0, bw1, b0, b1; int label; };
+__device__ __forceinline__ void head_prefetch(const ChainArgs& a, HeadInputs& hi, int seg, int row_blk, int rows_valid, int t) {
+    const HeadArgs& h = a.head;
+    const int lane = t & 63, lc = lane & 31, wave = t >> 6;
+    const int k = min(t & (CH_PW - 1), h.feat_valid - 1), j = min(wave * 32 + lc, h.feat_valid - 1);
+    hi.w0 = *(const f32x4*)(h.w + (long)k * h.ldw); hi.w1 = *(const f32x4*)(h.w + (long)k * h.ldw + 4);
+    hi.bw0 = *(const f32x4*)(h.w + (long)j * h.ldw); hi.bw1 = *(const f32x4*)(h.w + (long)j * h.ldw + 4);
+    hi.b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; hi.b1 = hi.b0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { hi.b0[c] = h.b[min(c, h.classes - 1)]; hi.b1[c] = h.b[min(4 + c, h.classes - 1)]; }
+    hi.label = 0;
+    if (h.seg_kind[seg] == HEAD_LAB) {
+        const long lo = h.labels_stream ? (long)h.st->batch * h.rows : 0;
+        hi.label = h.labels[lo + row_blk + min(lane, rows_valid - 1)];
+    }
+}
+
+__device__ __forceinline__ void chain_head(const ChainArgs& a, char* lds, Stream& sm, const HeadInputs& hi, const uint32_t (&mw)[2][2], int seg,
+                                           int rb, int nrb, int row_blk, int rows_valid, int t) {
     const HeadArgs& h = a.head;
     const char* fimg = lds + a.head_f_off;
-    float* w_lds = (float*)(lds + a.head_scratch_off);        // [feat][KMAX]
-    float* dl_lds = w_lds + h.feat * KMAX;                    // [64][KMAX]
-    float* red = dl_lds + CH_ROWS * KMAX;                     // [8 waves][16]
-    float* comb = red + 128;                                   // [feat][12]: second row-half's partial sums
-    const int lane = t & 63, wave = t >> 6;
+    char* oimg = lds + a.head_o_off;
+    __bf16* w6t = (__bf16*)(lds + a.head_scratch_off);        // [3][KMAX][CH_PW]
+    __bf16* dl_rc = w6t + 3 * KMAX * CH_PW;                   // [3][CH_ROWS][KMAX]   dlogits addends, row-major
+    __bf16* dl_t = dl_rc + 3 * CH_ROWS * KMAX;                // [3][KMAX][CH_ROWS]   ... class-major
+    float* lpart = (float*)oimg;                              // [8 waves][CH_ROWS][KMAX]: dead before the dpre image is written
+    const int lane = t & 63, lc = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int kind = h.seg_kind[seg];
     const int blk = seg * nrb + rb;
+    const bf16x8 zero8 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 
-    for (int k = t; k < h.feat; k += CH_THREADS) {
-        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
-        if (k < h.feat_valid) { w0 = *(const f32x4*)(h.w + (long)k * h.ldw); w1 = *(const f32x4*)(h.w + (long)k * h.ldw + 4); }
+    if (!(a.ablate & CH_ABL_COPY)) flush_copy(sm, rows_valid, t);      // the feature image -> HBM (no DMA wait follows inside the head)
+    // ---- 1. W6: thread <-> feature ----
+    if (t < CH_PW) {
+        const f32x4 w0 = hi.w0, w1 = hi.w1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { if (c >= h.classes) w0[c] = 0.f; if (c + 4 >= h.classes) w1[c] = 0.f; }
-        *(f32x4*)(w_lds + k * KMAX) = w0; *(f32x4*)(w_lds + k * KMAX + 4) = w1;
-    }
-    __syncthreads();
-
-    // ---- logits: 8 lanes per row, each over an interleaved slice of the features ----
-    constexpr int LPR = CH_THREADS / CH_ROWS;
-    const int r = t / LPR, part = t % LPR;
-    float l[KMAX];
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c) l[c] = 0.f;
-#pragma unroll 4
-    for (int kk = 0; kk < h.feat / LPR; ++kk) {
-        const int k = kk * LPR + part;
-        const float fv = (float)*(const __bf16*)(fimg + act_off(r, k));
-        const f32x4 w0 = *(const f32x4*)(w_lds + k * KMAX), w1 = *(const f32x4*)(w_lds + k * KMAX + 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { l[c] = fmaf(fv, w0[c], l[c]); l[4 + c] = fmaf(fv, w1[c], l[4 + c]); }
-    }
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c) {
-#pragma unroll
-        for (int m = 1; m < LPR; m <<= 1) l[c] += __shfl_xor(l[c], m, 64);
-    }
-    const int row = row_blk + r;
-    const bool rowvalid = r < rows_valid;
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c) {
-        if (c < h.classes) { l[c] += h.b[c]; mx = fmaxf(mx, l[c]); }
-    }
-    int am = 0;
-    float se = 0.f, p[KMAX];
-#pragma unroll
-    for (int c = KMAX - 1; c >= 0; --c) {
-        p[c] = (c < h.classes) ? expf(l[c] - mx) : 0.f;
-        se += p[c];
-        if (c < h.classes && l[c] == mx) am = c;          // ties -> first index (theano argmax)
-    }
-    const float lse = mx + logf(se);
-    const float inv_se = 1.0f / se;
-    float loss0 = 0.f, loss1 = 0.f, err = 0.f;
-    float dl[KMAX];
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c) dl[c] = 0.f;
-    if (rowvalid) {
-        if (kind == HEAD_LAB) {
-            const long lo = h.labels_stream ? (long)h.st->batch * h.rows : 0;
-            const int y = h.labels[lo + row];
-            err = (am != y) ? 1.f : 0.f;
-            float ly = 0.f;
-#pragma unroll
-            for (int c = 0; c < KMAX; ++c) {
-                if (c == y) ly = l[c];
-                dl[c] = (p[c] * inv_se - (c == y ? 1.f : 0.f)) * h.inv_count;
-            }
-            loss0 = lse - ly;
-        } else {
-            const float sg = sigmoid_f(lse), sp = softplus_f(lse);
-            const float k = 0.5f * h.inv_count * h.unl_weight * (kind == HEAD_UNL ? (sg - 1.0f) : sg);
-            loss1 = (kind == HEAD_UNL) ? 0.5f * (sp - lse) : 0.5f * sp;
-#pragma unroll
-            for (int c = 0; c < KMAX; ++c) dl[c] = k * p[c] * inv_se;
+        for (int c = 0; c < KMAX; ++c) {
+            const float wv = (t < h.feat_valid && c < h.classes) ? (c < 4 ? w0[c & 3] : w1[c & 3]) : 0.f;
+            __bf16 p0, p1, p2;
+            split3(wv, p0, p1, p2);
+            w6t[(0 * KMAX + c) * CH_PW + t] = p0; w6t[(1 * KMAX + c) * CH_PW + t] = p1; w6t[(2 * KMAX + c) * CH_PW + t] = p2;
         }
     }
-    if (part == 0) {
-        *(f32x4*)(dl_lds + r * KMAX) = (f32x4){dl[0], dl[1], dl[2], dl[3]};
-        *(f32x4*)(dl_lds + r * KMAX + 4) = (f32x4){dl[4], dl[5], dl[6], dl[7]};
-    } else { loss0 = 0.f; loss1 = 0.f; err = 0.f; }
-    loss0 = wave_sum(loss0); loss1 = wave_sum(loss1); err = wave_sum(err);
-    // db6 = column sums of dlogits: the lanes with part != 0 carry zeros
-    float dsum[KMAX];
+    // B operand of product 4 (k = class, column = feature 32 wave + lc): the eight class weights of this lane's feature
+    bf16x8 bw[3] = {zero8, zero8, zero8};
+    {
+        const int j = wave * 32 + lc;
+        const f32x4 w0 = hi.bw0, w1 = hi.bw1;
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c) dsum[c] = wave_sum(part == 0 ? dl[c] : 0.f);
-    if (lane == 0) {
-        red[wave * 16 + 0] = loss0; red[wave * 16 + 1] = loss1; red[wave * 16 + 2] = err;
-#pragma unroll
-        for (int c = 0; c < KMAX; ++c) red[wave * 16 + 4 + c] = dsum[c];
+        for (int c = 0; c < KMAX; ++c) {
+            const float wv = (lh == 0 && j < h.feat_valid && c < h.classes) ? (c < 4 ? w0[c & 3] : w1[c & 3]) : 0.f;      // lh = 1: k = 8 .. 15, zeros
+            __bf16 p0, p1, p2;
+            split3(wv, p0, p1, p2);
+            bw[0][c] = p0; bw[1][c] = p1; bw[2][c] = p2;
+        }
     }
-    __syncthreads();
+    lds_barrier();
+
+    // ---- 2. logits: this wave's 32 features of the reduction ----
+    {
+        f32x16 acc[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kg = 2 * wave + u;                      // k-step: features 16 kg .. 16 kg + 15
+            if (16 * kg < h.feat) {                           // (wave-uniform)
+                const char* As = fimg + (kg >> 2) * (CH_ROWS * 128);
+                const int ch = (kg & 3) * 2 + lh;
+                const bf16x8 fa0 = *(const bf16x8*)(As + kc_off(lc, ch)), fa1 = *(const bf16x8*)(As + kc_off(32 + lc, ch));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    bf16x8 fb = *(const bf16x8*)(w6t + (p * KMAX + (lc & (KMAX - 1))) * CH_PW + 16 * kg + 8 * lh);
+                    if (lc >= KMAX) fb = zero8;               // columns 8 .. 31 of the product are padding
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1], 0, 0, 0);
+                }
+            }
+        }
+        if (lc < KMAX) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lpart[(wave * CH_ROWS + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * KMAX + lc] = acc[mi][r];
+        }
+    }
+    lds_barrier();
+
+    // ---- 3. per row (wave 0: lane <-> row): losses, error, dlogits ----
     float* part_row = h.part + (long)blk * h.part_stride;
-    if (t < 4 + KMAX) {
-        float s0 = 0.f;
-        for (int w = 0; w < CH_THREADS / 64; ++w) s0 += red[w * 16 + t];
-        if (t < 3) h.loss_part[blk * 4 + t] = s0;
-        else if (t == 3) h.loss_part[blk * 4 + 3] = 0.f;
-        else part_row[h.off_db + t - 4] = s0;
-    }
-
-    // ---- backward of the last dense: two threads per feature column j, 32 rows each ----
-    char* oimg = lds + a.head_o_off;
-    const int j = t & 255, half = t >> 8;
-    float dw[KMAX], dbf = 0.f;
+    if (wave == 0) {
+        const int r = lane;
+        float l[KMAX];
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c) dw[c] = 0.f;
-    if (j < h.feat) {
-        float wj[KMAX];
+        for (int c = 0; c < KMAX; ++c) l[c] = 0.f;
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) wj[c] = w_lds[j * KMAX + c];
-#pragma unroll 4
-        for (int rr = half * 32; rr < half * 32 + 32; ++rr) {
-            const float fv = (float)*(const __bf16*)(fimg + act_off(rr, j));
-            const f32x4 d0 = *(const f32x4*)(dl_lds + rr * KMAX), d1 = *(const f32x4*)(dl_lds + rr * KMAX + 4);
-            float dfe = 0.f;
+        for (int w = 0; w < CH_THREADS / 64; ++w) {
+            const f32x4 p0 = *(const f32x4*)(lpart + (w * CH_ROWS + r) * KMAX), p1 = *(const f32x4*)(lpart + (w * CH_ROWS + r) * KMAX + 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                dfe = fmaf(d0[c], wj[c], dfe); dfe = fmaf(d1[c], wj[4 + c], dfe);
-                dw[c] = fmaf(fv, d0[c], dw[c]); dw[4 + c] = fmaf(fv, d1[c], dw[4 + c]);
+            for (int c = 0; c < 4; ++c) { l[c] += p0[c]; l[4 + c] += p1[c]; }
+        }
+        const bool rowvalid = r < rows_valid;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+            if (c < h.classes) { l[c] += (c < 4 ? hi.b0[c & 3] : hi.b1[c & 3]); mx = fmaxf(mx, l[c]); }
+        }
+        int am = 0;
+        float se = 0.f, p[KMAX];
+#pragma unroll
+        for (int c = KMAX - 1; c >= 0; --c) {
+            p[c] = (c < h.classes) ? expf(l[c] - mx) : 0.f;
+            se += p[c];
+            if (c < h.classes && l[c] == mx) am = c;          // ties -> first index (theano argmax)
+        }
+        const float lse = mx + logf(se);
+        const float inv_se = 1.0f / se;
+        float loss0 = 0.f, loss1 = 0.f, err = 0.f;
+        float dl[KMAX];
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) dl[c] = 0.f;
+        if (rowvalid) {
+            if (kind == HEAD_LAB) {
+                const int y = hi.label;
+                err = (am != y) ? 1.f : 0.f;
+                float ly = 0.f;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) {
+                    if (c == y) ly = l[c];
+                    dl[c] = (p[c] * inv_se - (c == y ? 1.f : 0.f)) * h.inv_count;
+                }
+                loss0 = lse - ly;
+            } else {
+                const float sg = sigmoid_f(lse), sp = softplus_f(lse);
+                const float k = 0.5f * h.inv_count * h.unl_weight * (kind == HEAD_UNL ? (sg - 1.0f) : sg);
+                loss1 = (kind == HEAD_UNL) ? 0.5f * (sp - lse) : 0.5f * sp;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) dl[c] = k * p[c] * inv_se;
             }
-            const float dp = (fv > 0.f) ? dfe : 0.f;
-            *(__bf16*)(oimg + act_off(rr, j)) = (__bf16)dp;
-            dbf += dp;
         }
-        if (half == 1) {
+        bf16x8 d3[3];
 #pragma unroll
-            for (int c = 0; c < KMAX; ++c) comb[j * 12 + c] = dw[c];
-            comb[j * 12 + 8] = dbf;
+        for (int c = 0; c < KMAX; ++c) {
+            __bf16 p0, p1, p2;
+            split3(dl[c], p0, p1, p2);
+            d3[0][c] = p0; d3[1][c] = p1; d3[2][c] = p2;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            *(bf16x8*)(dl_rc + (q * CH_ROWS + r) * KMAX) = d3[q];
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) dl_t[(q * KMAX + c) * CH_ROWS + r] = d3[q][c];
+        }
+        loss0 = wave_sum(loss0); loss1 = wave_sum(loss1); err = wave_sum(err);
+        float dsum[KMAX];                                     // db6 = column sums of dlogits
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) dsum[c] = wave_sum(dl[c]);
+        if (lane == 0) {
+            *(f32x4*)(h.loss_part + blk * 4) = (f32x4){loss0, loss1, err, 0.f};
+            *(f32x4*)(part_row + h.off_db) = (f32x4){dsum[0], dsum[1], dsum[2], dsum[3]};
+            *(f32x4*)(part_row + h.off_db + 4) = (f32x4){dsum[4], dsum[5], dsum[6], dsum[7]};
         }
     }
-    __syncthreads();
-    if (half == 0 && j < h.feat) {
+    lds_barrier();
+
+    // ---- 4. dL/d(pre5) = (dlogits W6^T) * relu'(pre5) for columns 32 wave .. + 31: the next product's A image ----
+    {
+        f32x16 acc[2];
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) dw[c] += comb[j * 12 + c];
-        dbf += comb[j * 12 + 8];
-        *(f32x4*)(part_row + (long)j * KMAX) = (f32x4){dw[0], dw[1], dw[2], dw[3]};
-        *(f32x4*)(part_row + (long)j * KMAX + 4) = (f32x4){dw[4], dw[5], dw[6], dw[7]};
-        part_row[h.off_dbf + j] = dbf;
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        bf16x8 da[2][3];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                da[mi][q] = *(const bf16x8*)(dl_rc + (q * CH_ROWS + mi * 32 + lc) * KMAX);
+                if (lh) da[mi][q] = zero8;                    // k = 8 .. 15: padding
+            }
+        // addend pairs down to 2^-24 of the product: (hi, hi) (hi, mid) (mid, hi) (hi, lo) (lo, hi) (mid, mid)
+        constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+        for (int i = 5; i >= 0; --i)                          // smallest terms first
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[mi][PA[i]], bw[PB[i]], acc[mi], 0, 0, 0);
+        const int cip = wave * 32 + lc;
+        int obase[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            obase[i] = (cip >> 6) * (CH_ROWS * 128) + lh * 512 + (((((cip & 63) >> 3) ^ (lh << 1)) ^ ((i & 1) | ((i >> 1) << 2))) << 4) + (cip & 7) * 2;
+        float s1 = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float av = acc[mi][r];
+                const float v = ((mw[0][mi] >> r) & 1u) ? av : 0.f;         // (a select: see chain_gemm)
+                s1 += v;
+                *(__bf16*)(oimg + obase[((r >> 1) & 1) | (((r >> 2) & 1) << 1)] + (mi * 32 + (r & 3) + 8 * (r >> 2)) * 128) = (__bf16)v;
+            }
+        s1 += __shfl_xor(s1, 32, 64);
+        if (lh == 0 && cip < h.feat) part_row[h.off_dbf + cip] = s1;       // bias gradient of the feature layer
     }
-    // dL/d(pre5): the next product's A image is complete (barrier above); its copy for the weight-gradient launch
-    copy_out(oimg, (__bf16*)h.dpre + (long)seg * h.dpre_bs + (long)row_blk * h.ldd, h.ldd, 0, h.feat, rows_valid, t);
+    // ---- 5. dW6^T [class][feature] = dlogits^T F, features 32 wave .. + 31 ----
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+        const int f0 = wave * 32 + (g4 & 1) * 16 + 4 * pp;
+#pragma unroll
+        for (int ks = 0; ks < CH_ROWS / 16; ++ks) {
+            // B fragment: eight consecutive rows (k) of this lane's feature column, by the transposing read
+            const int m0 = ks * 16 + (g4 >> 1) * 8 + q;
+            const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(fimg + act_off(m0, f0)));
+            const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(fimg + act_off(m0 + 4, f0)));
+            const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int p = 2; p >= 0; --p) {
+                bf16x8 fa = *(const bf16x8*)(dl_t + (p * KMAX + (lc & (KMAX - 1))) * CH_ROWS + 16 * ks + 8 * lh);
+                if (lc >= KMAX) fa = zero8;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+            }
+        }
+        const int j = wave * 32 + lc;                         // registers 0 .. 3 = classes 4 lh .. 4 lh + 3 of feature j
+        if (j < h.feat) *(f32x4*)(part_row + (long)j * KMAX + 4 * lh) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    }
+    lds_barrier();
+    // dL/d(pre5): the next product's A image is complete; its copy for the weight-gradient launch leaves at the end of that
+    // product's k-loop
+    sm.cp_img = oimg; sm.cp_out = (__bf16*)h.dpre + (long)seg * h.dpre_bs + (long)row_blk * h.ldd;
+    sm.cp_ldo = h.ldd; sm.cp_col0 = 0; sm.cp_ncols = h.feat;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -322,14 +451,8 @@ __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int 
     }
     __syncthreads();
     CH_STAMP(6);
-    copy_out(img, (__bf16*)f.dpre + (long)row_blk * f.ldd, f.ldd, 0, f.feat, rows_valid, t);
-    CH_STAMP(7);
+    CH_STAMP(7);        // (the image's copy to HBM is deferred to the end of the first product's k-loop: see Stream)
 }
-
-// Shared state of the weight-tile stream of one block (all wave-uniform)
-struct Stream {
-    BCursor pc; bool more; int gtile; int first_wait;
-};
 
 // one dense product of the chain on the block's rows.  MODE is compile-time; `bias` (forward) and `mw` (the relu-mask words
 // of the output tile: read by dX, returned by forward) live in registers, loaded or produced before this call.
@@ -366,17 +489,22 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
             for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
         CH_STAMP(1);               // pass setup
         for (int kt = 0; kt < nk; ++kt) {
-            wait_vm(kt == 0 ? sm.first_wait : 0);          // this wave's pieces of tile gtile have landed
+            // No workgroup barrier inside the k-loop: a wave reads only ITS OWN 32 columns of a weight tile, and those are
+            // exactly the pieces it loads itself (issue_btile), so its own counted vmcnt orders the LDS-DMA before its reads;
+            // the stage refilled below was last read by this wave during tile gtile - 1, whose fragments its MFMAs have
+            // already consumed.  The A image is read-only for the whole product (completed behind the barrier that ended the
+            // previous product / the prologue).  The waves of a block drift apart inside a product -- one wave's MFMAs beside
+            // another's epilogue -- and meet again at the image barrier that ends the pass.
+            if (!(a.ablate & CH_ABL_STREAM)) wait_vm(0);          // this wave's pieces of tile gtile have landed (anything older: long done)
             CH_STAMP(3);                                   // wait for the weight tile
-            __builtin_amdgcn_s_barrier();                  // ... everyone's; everyone is done with tile gtile - 1 and with the A image writes
-            asm volatile("" ::: "memory");
-            CH_STAMP(4);                                   // barrier
-            if (sm.more) { issue_btile(a, sm.pc, lds + CH_RING + ((sm.gtile + 1) & 1) * CH_STAGE_BYTES, wave, lane); sm.more = advance(a, sm.pc); }
+            if (sm.more && (a.ablate & CH_ABL_STREAM)) sm.more = advance(a, sm.pc);
+            else if (sm.more) { issue_btile(a, sm.pc, lds + CH_RING + ((sm.gtile + 1) & 1) * CH_STAGE_BYTES, wave, lane); sm.more = advance(a, sm.pc); }
             const char* As = lds + a_off + kt * (CH_ROWS * 128);
             const char* Bs = lds + CH_RING + (sm.gtile & 1) * CH_STAGE_BYTES;
             ++sm.gtile;
             // fragments of two k-steps per batch: their LDS latency is paid once per batch (the other wave of the SIMD
             // covers the rest); a deeper batch costs registers the epilogue needs
+            if (a.ablate & CH_ABL_MFMA) continue;
 #pragma unroll
             for (int kg = 0; kg < 4; kg += 2) {
                 bf16x8 fa[2][2], fb[2];
@@ -396,6 +524,10 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
             CH_STAMP(5);                                   // tile issue + fragment reads + MFMAs
         }
 
+        if (!(a.ablate & CH_ABL_COPY)) flush_copy(sm, rows_valid, t);      // the previous pass's image -> HBM (see Stream)
+        // every pass of a product assembles its 256 columns in the SAME image: a second pass may only overwrite them when every
+        // wave has copied the first pass's out (the only such product, dX through D3, ends the chain)
+        if (pass > 0) lds_barrier();
         // ---- epilogue: bias / relu / mask / noise, bf16 into the output image, column sums ----
         char* oimg = lds + o_off;
         const int cip = wave * 32 + lc;                    // column inside the pass = column of the output image
@@ -410,7 +542,9 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
         auto ostore = [&](int mi, int r, float o) {
             *(__bf16*)(oimg + obase[((r >> 1) & 1) | (((r >> 2) & 1) << 1)] + (mi * 32 + (r & 3) + 8 * (r >> 2)) * 128) = (__bf16)o;
         };
-        if constexpr (fwd) {
+        if (a.ablate & CH_ABL_EPI) {
+            if (acc[0][0] == 12345.678f) ostore(0, 0, s1);
+        } else if constexpr (fwd) {
             const float bv = colvalid ? bias : 0.f;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
@@ -460,12 +594,10 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
         }
         CH_STAMP(6);                                       // epilogue math + image writes
         lds_barrier();                                     // the output image is complete
-        if (op.out)
-            copy_out(oimg, op.out + (long)seg * op.out_bs + (long)row_blk * op.ldo, op.ldo, pass * CH_PW, N, rows_valid, t);
-        // The copy-out stores are the youngest VMEM ops of this wave and may stay in flight over the next tile wait --
-        // but only when every wave really issued all of them (a full block and a full pass; a wave whose lanes are
-        // all predicated off may skip the instruction, and an over-counted wait would not cover the weight tile).
-        sm.first_wait = (op.out && rows_valid == CH_ROWS && N - pass * CH_PW >= CH_PW) ? CH_ROWS * CH_PW / 8 / CH_THREADS : 0;
+        if (op.out) {                                      // this pass's columns: copied out at the end of the next k-loop
+            sm.cp_img = oimg; sm.cp_out = op.out + (long)seg * op.out_bs + (long)row_blk * op.ldo;
+            sm.cp_ldo = op.ldo; sm.cp_col0 = pass * CH_PW; sm.cp_ncols = N;
+        }
         CH_STAMP(7);                                       // image barrier + copy-out issue
     }
 }
@@ -521,17 +653,13 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
         for (int i = 0; i < 3; ++i) { const float bv = a.op[i].bias[min(col0, a.op[i].n_valid - 1)]; bias[i] = col0 < a.op[i].n_valid ? bv : 0.f; }
     }
     if constexpr (VARIANT == CH_V_DTAIL) load_mask_words(a, a.op[6], mwC, seg, row_blk, wave, lc, lh);      // dX through D3 needs D2's mask
+    HeadInputs hin;
+    if constexpr (VARIANT == CH_V_DTAIL) head_prefetch(a, hin, seg, row_blk, rows_valid, t);
     if constexpr (VARIANT == CH_V_GBWD) {
         load_mask_words(a, a.op[0], mwA, seg, row_blk, wave, lc, lh);
         load_mask_words(a, a.op[1], mwB, seg, row_blk, wave, lc, lh);
         load_mask_words(a, a.op[2], mwC, seg, row_blk, wave, lc, lh);
     }
-
-    // ---- the weight-tile stream ----
-    Stream sm;
-    sm.pc = BCursor{next_gemm(a, 0), 0, 0};
-    sm.more = sm.pc.op < a.nops; sm.gtile = 0; sm.first_wait = 0;
-    if (sm.more) { issue_btile(a, sm.pc, lds + CH_RING, wave, lane); sm.more = advance(a, sm.pc); }
 
     // ---- first A image ----
     const int a0_off = a.op[0].a_off;
@@ -545,8 +673,20 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
             const int voff = (int)(((long)(row_blk + R) * a.lda + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
             glds16(rsA, lds + a0_off + kt * (CH_ROWS * 128) + (pce & 7) * 1024, voff, kt * 128);
         }
+    }
+    // ---- the weight-tile stream (per wave: its own 32 columns of every tile) ----
+    Stream sm;
+    sm.pc = BCursor{next_gemm(a, 0), 0, 0};
+    sm.more = sm.pc.op < a.nops; sm.gtile = 0; sm.cp_img = nullptr;
+    if (sm.more) { issue_btile(a, sm.pc, lds + CH_RING, wave, lane); sm.more = advance(a, sm.pc); }
+    if constexpr (VARIANT != CH_V_GBWD) {
+        wait_vm(4);                // this wave's pieces of the A image have landed (the 4 weight-tile pieces are younger) ...
+        __builtin_amdgcn_s_barrier();      // ... everyone's: the k-loops below run without workgroup barriers
+        asm volatile("" ::: "memory");
     } else {
-        chain_fmgrad(a, lds, a0_off, rb, row_blk, rows_valid, t CH_ST_ARGS);
+        chain_fmgrad(a, lds, a0_off, rb, row_blk, rows_valid, t CH_ST_ARGS);      // (ends with a workgroup barrier)
+        sm.cp_img = lds + a0_off; sm.cp_out = (__bf16*)a.fm.dpre + (long)row_blk * a.fm.ldd;
+        sm.cp_ldo = a.fm.ldd; sm.cp_col0 = 0; sm.cp_ncols = a.fm.feat;
     }
     CH_STAMP(0);                   // prologue (epilogue inputs, first tile issue, A image)
 
@@ -563,12 +703,10 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
         CH_GEMM(CH_FWD_RELU, 0, bias[0], mwB);
         CH_GEMM(CH_FWD_RELU, 1, bias[1], mwA);
         CH_GEMM(CH_FWD_RELU, 2, bias[2], mw4);
-        wait_vm(0);                // (the pending weight tile is simply waited for: the head is long)
-        lds_barrier();
-        CH_STAMP(1);
-        chain_head(a, lds, seg, rb, nrb, row_blk, rows_valid, t);
+        CH_STAMP(1);               // (the feature image is complete: chain_gemm ended with the image barrier; the weight tile in
+                                   //  flight lands in the ring, which the head does not touch)
+        if (!(a.ablate & CH_ABL_HEAD)) chain_head(a, lds, sm, hin, mw4, seg, rb, nrb, row_blk, rows_valid, t);
         CH_STAMP(2);               // loss head
-        sm.first_wait = 0;
         CH_GEMM(CH_DX_RELU, 4, 0.f, mwA);       // dX through D5 * relu'(D4)
         CH_GEMM(CH_DX_RELU, 5, 0.f, mwB);       // dX through D4 * relu'(D3)
         CH_GEMM(CH_DX_RELU, 6, 0.f, mwC);       // dX through D3 * relu'(D2)
@@ -583,6 +721,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
         CH_GEMM(CH_DX_RELU, 2, 0.f, mwC);
     }
 #undef CH_GEMM
+    if (!(a.ablate & CH_ABL_COPY)) flush_copy(sm, rows_valid, t);      // the last image
 #ifdef MRGAN_STAMPS
     if (a.stamps && t == 0)
         for (int i = 0; i < 8; ++i) a.stamps[(long)blockIdx.x * 8 + i] = st_acc[i];

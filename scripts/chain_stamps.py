@@ -9,6 +9,9 @@ B, D = 4096, 512
 cfg = E.default_config(D, B)
 cfg.dtype, cfg.seed = 1, 1
 eng = E.Engine(cfg, "cuda:0")
+import os
+if os.environ.get("CHAIN_ABLATE"):
+    eng.debug_ablate(int(os.environ["CHAIN_ABLATE"]))      # CH_ABL_* bits (chain.h): timing experiments, results wrong
 rs = np.random.RandomState(0)
 for net in (E.NET_G, E.NET_D):
     ws = []
