@@ -50,32 +50,27 @@ __device__ __forceinline__ void wait_vm(int n) {
 #define CH_STAMP(i)
 #endif
 
-struct BCursor { int op, pass, kt; };
-
-__device__ __forceinline__ int next_gemm(const ChainArgs& a, int i) {
-    while (i < a.nops && a.op[i].kind != CH_OP_GEMM) ++i;
-    return i;
-}
-__device__ __forceinline__ bool advance(const ChainArgs& a, BCursor& c) {
-    const ChainOp& op = a.op[c.op];
-    if (++c.kt < op.K / 64) return true;
-    c.kt = 0;
-    if (++c.pass < (op.N + CH_PW - 1) / CH_PW) return true;
-    c.pass = 0;
-    c.op = next_gemm(a, c.op + 1);
-    return c.op < a.nops;
-}
-// one weight tile [256 columns][64 k] of (product, pass, k-tile) into a ring stage: 4 wave-instructions per wave
-__device__ __forceinline__ void issue_btile(const ChainArgs& a, const BCursor& c, char* stage, int wave, int lane) {
-    const ChainOp& op = a.op[c.op];
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)op.W, 0, (int)((long)op.N * op.K * 2), 0x00020000);
+// The weight tiles of a chain form one flat sequence over (product, pass, k-tile): the tile issued while tile g is consumed is
+// tile g + 1 -- of this product, or the first tile of the next one, whose three scalars (Bt, K, N) the caller passes along.
+// Everything the issue needs lives in registers for the whole product (a descriptor in SGPRs, four per-lane row offsets): no
+// load from the argument block inside the k-loops.
+struct BTile {
+    __amdgpu_buffer_rsrc_t rs; int voff[4]; int pass_bytes;       // byte offset of 256 more columns of Bt
+};
+__device__ __forceinline__ void btile_setup(BTile& b, const __bf16* W, int K, int N, int wave, int lane) {
+    b.rs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)((long)N * K * 2), 0x00020000);      // rows >= N of Bt read as zeros
     const int lrow = lane >> 3, lp = lane & 7;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int R = (wave * 4 + i) * 8 + lrow;                 // column of the pass: rows >= N of Bt read as zeros
-        const int voff = (int)(((long)(c.pass * CH_PW + R) * op.K + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
-        glds16(rs, stage + (wave * 4 + i) * 1024, voff, c.kt * 128);
+        const int R = (wave * 4 + i) * 8 + lrow;                   // column of the pass = row of Bt
+        b.voff[i] = (R * K + ((lp ^ ((R >> 1) & 7)) << 3)) * 2;
     }
+    b.pass_bytes = CH_PW * K * 2;
+}
+// one weight tile [256 columns][64 k] into a ring stage: 4 wave-instructions per wave, each wave its own 32 columns
+__device__ __forceinline__ void issue_btile(const BTile& b, int pass, int kt, char* stage, int wave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(b.rs, stage + (wave * 4 + i) * 1024, b.voff[i] + pass * b.pass_bytes, kt * 128);
 }
 
 // copy a [64 rows][256 columns] bf16 LDS image (columns col0 .. of the global tensor) out with 16-byte stores
@@ -90,7 +85,7 @@ __device__ __forceinline__ void copy_out(const char* img, __bf16* out, int ldo, 
 
 // Shared state of the weight-tile stream of one block (all wave-uniform)
 struct Stream {
-    BCursor pc; bool more; int gtile;
+    int gtile;                 // tiles consumed so far: tile g lives in ring stage g & 1
     // The copy of a finished output image to HBM is DEFERRED to the end of the next pass's k-loop.  Stores count in vmcnt in issue
     // order with the weight-tile DMAs: issued right behind the image barrier (round 2) they sat in front of the next tile's
     // DMA, and the wait for that tile -- one k-tile of MFMAs later -- also waited for the stores' acknowledgement (~1 us per
@@ -457,7 +452,8 @@ __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int 
 // one dense product of the chain on the block's rows.  MODE is compile-time; `bias` (forward) and `mw` (the relu-mask words
 // of the output tile: read by dX, returned by forward) live in registers, loaded or produced before this call.
 template <int MODE>
-__device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op, char* lds, Stream& sm, const float bias,
+__device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op, const __bf16* nextW, const int nextK, const int nextN,
+                                           char* lds, Stream& sm, const float bias,
                                            uint32_t (&mw)[2][2], const int seg, const int nrb, const int rb, const int row_blk,
                                            const int rows_valid, const uint32_t iter, const i32x4 hfrag, const int t
 #ifdef MRGAN_STAMPS
@@ -477,6 +473,8 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
         for (int mi = 0; mi < 2; ++mi) rowhash[mi] = noise_rowhash(nkey, a.row0 + (uint32_t)(row_blk + mi * 32 + lc));
     }
     uint16_t* mask = op.mask ? op.mask + (long)seg * op.mask_bs : nullptr;
+    BTile bt;
+    btile_setup(bt, op.W, K, N, wave, lane);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if (pass >= npass) break;
@@ -497,8 +495,12 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
             // another's epilogue -- and meet again at the image barrier that ends the pass.
             if (!(a.ablate & CH_ABL_STREAM)) wait_vm(0);          // this wave's pieces of tile gtile have landed (anything older: long done)
             CH_STAMP(3);                                   // wait for the weight tile
-            if (sm.more && (a.ablate & CH_ABL_STREAM)) sm.more = advance(a, sm.pc);
-            else if (sm.more) { issue_btile(a, sm.pc, lds + CH_RING + ((sm.gtile + 1) & 1) * CH_STAGE_BYTES, wave, lane); sm.more = advance(a, sm.pc); }
+            if (!(a.ablate & CH_ABL_STREAM)) {
+                char* stage = lds + CH_RING + ((sm.gtile + 1) & 1) * CH_STAGE_BYTES;
+                if (kt + 1 < nk) issue_btile(bt, pass, kt + 1, stage, wave);
+                else if (pass + 1 < npass) issue_btile(bt, pass + 1, 0, stage, wave);
+                else if (nextW) { BTile nb; btile_setup(nb, nextW, nextK, nextN, wave, lane); issue_btile(nb, 0, 0, stage, wave); }
+            }
             const char* As = lds + a_off + kt * (CH_ROWS * 128);
             const char* Bs = lds + CH_RING + (sm.gtile & 1) * CH_STAGE_BYTES;
             ++sm.gtile;
@@ -540,6 +542,9 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
         const float sig = (noisy && colvalid) ? op.sigma * NOISE_SCALE : 0.f;
         float s1 = 0.f;
         auto ostore = [&](int mi, int r, float o) {
+#ifdef MRGAN_CH_NO_OSTORE       // timing experiment (compile-time: a run-time test per element perturbs the epilogue it measures)
+            asm volatile("" :: "v"(o)); return;
+#endif
             *(__bf16*)(oimg + obase[((r >> 1) & 1) | (((r >> 2) & 1) << 1)] + (mi * 32 + (r & 3) + 8 * (r >> 2)) * 128) = (__bf16)o;
         };
         if (a.ablate & CH_ABL_EPI) {
@@ -676,9 +681,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     }
     // ---- the weight-tile stream (per wave: its own 32 columns of every tile) ----
     Stream sm;
-    sm.pc = BCursor{next_gemm(a, 0), 0, 0};
-    sm.more = sm.pc.op < a.nops; sm.gtile = 0; sm.cp_img = nullptr;
-    if (sm.more) { issue_btile(a, sm.pc, lds + CH_RING, wave, lane); sm.more = advance(a, sm.pc); }
+    sm.gtile = 0; sm.cp_img = nullptr;
+    { BTile b0; btile_setup(b0, a.op[0].W, a.op[0].K, a.op[0].N, wave, lane); issue_btile(b0, 0, 0, lds + CH_RING, wave); }
     if constexpr (VARIANT != CH_V_GBWD) {
         wait_vm(4);                // this wave's pieces of the A image have landed (the 4 weight-tile pieces are younger) ...
         __builtin_amdgcn_s_barrier();      // ... everyone's: the k-loops below run without workgroup barriers
@@ -696,29 +700,33 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     // pass pays ~2 k cycles of spill traffic
     auto opq = [](int i) { asm volatile("" : "+s"(i)); return i; };
     // ... and the descriptor is copied as a whole (wide scalar loads, one wait) instead of field by field at the points of use
-#define CH_GEMM(MODE, I, BIAS, MW) do { const ChainOp op_ = a.op[opq(I)]; chain_gemm<MODE>(a, op_, lds, sm, BIAS, MW, seg, nrb, rb, row_blk, rows_valid, iter, hfrag, t CH_ST_ARGS); } while (0)
+    // NEXT: index of the product that follows (-1: none) -- its first weight tile is issued during this product's last k-tile
+#define CH_GEMM(MODE, I, NEXT, BIAS, MW) do { const ChainOp op_ = a.op[opq(I)];                                                          \
+        const int nx_ = opq(NEXT < 0 ? 0 : NEXT);                                                                                      \
+        chain_gemm<MODE>(a, op_, NEXT < 0 ? nullptr : a.op[nx_].W, a.op[nx_].K, a.op[nx_].N, lds, sm, BIAS, MW, seg, nrb, rb, row_blk,  \
+                         rows_valid, iter, hfrag, t CH_ST_ARGS); } while (0)
     if constexpr (VARIANT == CH_V_DTAIL) {
         // D3 D4 D5 forward: the masks of D3 / D4 stay in registers for the way back
         uint32_t mw4[2][2];
-        CH_GEMM(CH_FWD_RELU, 0, bias[0], mwB);
-        CH_GEMM(CH_FWD_RELU, 1, bias[1], mwA);
-        CH_GEMM(CH_FWD_RELU, 2, bias[2], mw4);
+        CH_GEMM(CH_FWD_RELU, 0, 1, bias[0], mwB);
+        CH_GEMM(CH_FWD_RELU, 1, 2, bias[1], mwA);
+        CH_GEMM(CH_FWD_RELU, 2, 4, bias[2], mw4);
         CH_STAMP(1);               // (the feature image is complete: chain_gemm ended with the image barrier; the weight tile in
                                    //  flight lands in the ring, which the head does not touch)
         if (!(a.ablate & CH_ABL_HEAD)) chain_head(a, lds, sm, hin, mw4, seg, rb, nrb, row_blk, rows_valid, t);
         CH_STAMP(2);               // loss head
-        CH_GEMM(CH_DX_RELU, 4, 0.f, mwA);       // dX through D5 * relu'(D4)
-        CH_GEMM(CH_DX_RELU, 5, 0.f, mwB);       // dX through D4 * relu'(D3)
-        CH_GEMM(CH_DX_RELU, 6, 0.f, mwC);       // dX through D3 * relu'(D2)
+        CH_GEMM(CH_DX_RELU, 4, 5, 0.f, mwA);       // dX through D5 * relu'(D4)
+        CH_GEMM(CH_DX_RELU, 5, 6, 0.f, mwB);       // dX through D4 * relu'(D3)
+        CH_GEMM(CH_DX_RELU, 6, -1, 0.f, mwC);       // dX through D3 * relu'(D2)
     } else if constexpr (VARIANT == CH_V_GFWD) {
         uint32_t mwx[2][2];
-        CH_GEMM(CH_FWD_RELU, 0, bias[0], mwx);
-        CH_GEMM(CH_FWD_RELU, 1, bias[1], mwx);
-        CH_GEMM(CH_FWD_RELU, 2, bias[2], mwx);
+        CH_GEMM(CH_FWD_RELU, 0, 1, bias[0], mwx);
+        CH_GEMM(CH_FWD_RELU, 1, 2, bias[1], mwx);
+        CH_GEMM(CH_FWD_RELU, 2, -1, bias[2], mwx);
     } else {
-        CH_GEMM(CH_DX_RELU, 0, 0.f, mwA);
-        CH_GEMM(CH_DX_RELU, 1, 0.f, mwB);
-        CH_GEMM(CH_DX_RELU, 2, 0.f, mwC);
+        CH_GEMM(CH_DX_RELU, 0, 1, 0.f, mwA);
+        CH_GEMM(CH_DX_RELU, 1, 2, 0.f, mwB);
+        CH_GEMM(CH_DX_RELU, 2, -1, 0.f, mwC);
     }
 #undef CH_GEMM
     if (!(a.ablate & CH_ABL_COPY)) flush_copy(sm, rows_valid, t);      // the last image

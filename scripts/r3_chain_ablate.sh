@@ -1,7 +1,7 @@
 #!/bin/bash
 # wall time of the three chain launches with parts of the kernel switched off (results wrong; timing only)
 mkdir -p gpurun_out/r3c
-for ab in 0 256 512 1024 2048 4096 3072 4864 7936; do
+for ab in ${ABLS:-0 256 512 1024 2048 4096 3072 4864 7936}; do
   python bench.py --steps 50 --warmup 10 --no-cpu-baseline --min-seconds 0.05 --ablate $ab > gpurun_out/r3c/abl_$ab.json 2> gpurun_out/r3c/abl_$ab.err
   python - $ab <<'PY'
 import json, sys
