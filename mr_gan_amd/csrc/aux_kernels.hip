@@ -597,8 +597,11 @@ __device__ __forceinline__ f32x4 adam_sum_slabs(const float* g, long stride, int
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     __shared__ float tl[64 * 65];
     const int t = threadIdx.x;
-    if (blockIdx.x < a.ntiles) {
-    const AdamTile tile = a.tiles[blockIdx.x];
+    // block 0 is the serial one (next DevState with two double-precision pow(), the loss partials folded in a fixed order): first
+    // in dispatch order, so that it runs beside the tile blocks instead of behind them
+    const int tile_id = (int)blockIdx.x - 1;
+    if (tile_id >= 0) {
+    const AdamTile tile = a.tiles[tile_id];
     const float lr_t = a.st->lr_t;
     const int qpr = tile.cols >> 2;                       // four-element groups per row
     const int nq = tile.rows * qpr;
@@ -700,8 +703,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     }
     if (tile.w8_slot && a.mode != ADAM_REDUCE_ONLY) fp8_amax_commit(tile.w8_slot, w8_amax);
     }
-    // ---- the extra last block: the next sub-step's DevState, and this sub-step's loss partials ----
-    if (blockIdx.x == a.ntiles && t == 0 && a.next && a.mode != ADAM_REDUCE_ONLY) {
+    // ---- block 0: the next sub-step's DevState, and this sub-step's loss partials ----
+    if (tile_id < 0 && t == 0 && a.next && a.mode != ADAM_REDUCE_ONLY) {
         const DevState st = *a.st;
         DevState nx;
         nx.iter = st.iter + 1;
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         nx.pad = 0;
         *a.next = nx;
     }
-    if (blockIdx.x == a.ntiles && a.step_out) {
+    if (tile_id < 0 && a.step_out) {
         __shared__ float ms[3][256];
         float s[3] = {0.f, 0.f, 0.f};
         if (a.mode == ADAM_FROM_FLAT) { if (t == 0) for (int i = 0; i < 3; ++i) s[i] = a.flat_tail[i]; }

@@ -223,6 +223,7 @@ int validate(const mrgan_config& c) {
     return 0;
 }
 
+int count_adam_tiles(const std::vector<Tensor>& ts);
 // carve the workspace; with base == nullptr only computes the size
 int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     const mrgan_config& c = h->cfg;
@@ -374,12 +375,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     src(*h->g[2].b, h->cs_db3g, tm, h->Dp);
 
     // ---- Adam tile tables ------------------------------------------------------------------------------
-    auto count_tiles = [&](std::vector<Tensor>& ts) {
-        int n = 0;
-        for (auto& t : ts) n += ceil_div(t.prow, 64) * ceil_div(t.pcol, 64);
-        return n;
-    };
-    h->ntiles_g = count_tiles(h->gt); h->ntiles_d = count_tiles(h->dt);
+    h->ntiles_g = count_adam_tiles(h->gt); h->ntiles_d = count_adam_tiles(h->dt);
     h->tiles_g_dev = a.take<AdamTile>(h->ntiles_g);
     h->tiles_d_dev = a.take<AdamTile>(h->ntiles_d);
 
@@ -387,10 +383,26 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     return 0;
 }
 
+// Rows per Adam tile (one 256-thread block each).  The update is pure streaming (48 B per parameter in the bf16 mode) and a block's
+// loads are one dependent round: what hides the latency is blocks per CU.  64 x 64 tiles give the discriminator of the reference
+// 330 blocks on 256 CUs (15 us, 4 TB/s); 16-row tiles give 1 300.  Wide stacks have thousands of 64-row tiles already.
+int adam_tile_rows(const std::vector<Tensor>& ts) {
+    long n64 = 0;
+    for (auto& t : ts) n64 += (long)ceil_div(t.prow, 64) * ceil_div(t.pcol, 64);
+    return n64 >= 2048 ? 64 : 16;
+}
+int count_adam_tiles(const std::vector<Tensor>& ts) {
+    const int tr = adam_tile_rows(ts);
+    int n = 0;
+    for (auto& t : ts) n += ceil_div(t.prow, tr) * ceil_div(t.pcol, 64);
+    return n;
+}
+
 int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n, hipStream_t s) {
     std::vector<AdamTile> v;
+    const int TR = adam_tile_rows(ts);
     for (auto& t : ts)
-        for (int r0 = 0; r0 < t.prow; r0 += 64)
+        for (int r0 = 0; r0 < t.prow; r0 += TR)
             for (int c0 = 0; c0 < t.pcol; c0 += 64) {
                 AdamTile a;
                 const long off = (long)r0 * t.pcol + c0;
@@ -404,7 +416,7 @@ int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n,
                     if (&t == h->d[l].W) { a.w8 = h->w8[l] + off; a.w8t = h->w8t[l] + (long)c0 * t.prow + r0; a.w8_slot = h->slots + slot_w(l); }
                 if (h->fp8 && &t == h->g[1].W) { a.w8 = h->gw8 + off; a.w8t = h->gw8t + (long)c0 * t.prow + r0; a.w8_slot = h->slots + SLOT_GW; }
                 a.ld = t.pcol; a.ldt = t.prow;
-                a.rows = std::min(64, t.prow - r0); a.cols = std::min(64, t.pcol - c0);
+                a.rows = std::min(TR, t.prow - r0); a.cols = std::min(64, t.pcol - c0);
                 v.push_back(a);
             }
     if ((int)v.size() != n) return fail(-20, "tile count mismatch");
@@ -1740,8 +1752,8 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
 #ifdef MRGAN_STAMPS
     unsigned long long* stamps = nullptr;
     if (op != 2) {
-        HIPCHK(hipMalloc((void**)&stamps, 4096 * 8 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(stamps, 0, 4096 * 8 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void**)&stamps, 4096 * 12 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(stamps, 0, 4096 * 12 * sizeof(unsigned long long)));
         g.e.slab = (float*)stamps;
     }
 #endif
@@ -1759,12 +1771,13 @@ int mrgan_debug_gemm_time(int op, int m, int n, int k, int nbatch, int splits, i
     *avg_us = 1e3f * ms / (float)reps;
 #ifdef MRGAN_STAMPS
     if (stamps) {
-        std::vector<unsigned long long> hs(4096 * 8);
+        std::vector<unsigned long long> hs(4096 * 12);
         hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
-        double tot[6] = {0, 0, 0, 0, 0, 0}; int nb = 0;
-        for (int b = 0; b < 4096; ++b) if (hs[b * 8 + 2]) { ++nb; for (int i = 0; i < 6; ++i) tot[i] += (double)hs[b * 8 + i]; }
-        if (nb) fprintf(stderr, "  stamps (kcycles per block, %d blocks): setup %.1f | fill %.1f | mainloop %.1f | barrier %.1f | epilogue %.1f | tail-barrier %.1f\n",
-                        nb, tot[0] / nb / 1e3, tot[1] / nb / 1e3, tot[2] / nb / 1e3, tot[3] / nb / 1e3, tot[4] / nb / 1e3, tot[5] / nb / 1e3);
+        double tot[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int nb = 0;
+        for (int b = 0; b < 4096; ++b) if (hs[b * 12 + 2]) { ++nb; for (int i = 0; i < 10; ++i) tot[i] += (double)hs[b * 12 + i]; }
+        if (nb) fprintf(stderr, "  stamps (kcycles per block, %d blocks): setup %.1f | fill %.1f | mainloop %.1f | barrier %.1f | epilogue %.1f (math+staging %.1f, barrier %.1f, copy-out %.1f, column sums %.1f) | tail-barrier %.1f\n",
+                        nb, tot[0] / nb / 1e3, tot[1] / nb / 1e3, tot[2] / nb / 1e3, tot[3] / nb / 1e3, tot[4] / nb / 1e3, tot[6] / nb / 1e3, tot[7] / nb / 1e3, tot[8] / nb / 1e3,
+                        tot[9] / nb / 1e3, tot[5] / nb / 1e3);
         hipFree(stamps);
     }
 #endif

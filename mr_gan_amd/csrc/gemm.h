@@ -75,6 +75,7 @@ __device__ __forceinline__ uint32_t relu_mask_bit(const uint16_t* mask, int ldm,
 template <int MR, int NR>
 struct EpiPrefetch {
     float bias[NR];
+    float mu[NR], rstd[NR];      // DX with CS_SUM_XHAT: BatchNorm mean / 1/std of the wave's columns
     uint32_t mbits[MR][NR];
     uint32_t iter;               // DevState::iter for the noise key (FWD with noise)
 };
@@ -99,8 +100,18 @@ __device__ __forceinline__ void epilogue_prefetch(EpiPrefetch<MR, NR>& pf, const
 #pragma unroll
     for (int ni = 0; ni < NR; ++ni) {
         const int col = col_blk + (wn * NR + ni) * 32 + lc;
-        pf.bias[ni] = 0.f;
+        pf.bias[ni] = 0.f; pf.mu[ni] = 0.f; pf.rstd[ni] = 0.f;
         if constexpr (EPI == EPI_FWD) { if (col < e.n_valid && e.bias) pf.bias[ni] = e.bias[col]; }
+        if constexpr (EPI == EPI_DX) {
+            // (inside the column-sum pass these two loads were an exposed round trip per launch: 7.6 k cycles in the stamps of the
+            // generator's d(BatchNorm output) product)
+            if (e.cs_mode == CS_SUM_XHAT) {
+                const bool cok = col < e.n_valid && col < g.N;
+                const int cc = cok ? col : 0;
+                const float m = e.bn_mu[cc], r = e.bn_rstd[cc];
+                pf.mu[ni] = cok ? m : 0.f; pf.rstd[ni] = cok ? r : 0.f;
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < MR; ++mi) {
             pf.mbits[mi][ni] = 0;
@@ -127,7 +138,14 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                                          float* lds /* >= 2*WM*bn floats of scratch, disjoint from `tile` */,
                                          int bn /* block tile width */, T* tile = nullptr,
                                          const EpiPrefetch<MR, NR>* pf = nullptr,
-                                         const T* htile = nullptr /* STAGED: LDS copy [BM][bn] of the block's tile of e.h */) {
+                                         const T* htile = nullptr /* STAGED: LDS copy [BM][bn] of the block's tile of e.h */,
+                                         unsigned long long* est = nullptr /* make STAMPS=1: [4] cycle sums + [4] = previous stamp */) {
+#ifdef MRGAN_STAMPS
+#define EPI_STAMP(i) do { if (est) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); est[i] += n_ - est[4]; est[4] = n_; } } while (0)
+    if (est) est[4] = __builtin_amdgcn_s_memtime();
+#else
+#define EPI_STAMP(i)
+#endif
     const Epi& e = g.e;
     const int lc = lane & 31, lh = lane >> 5;
     const int M = g.M;
@@ -284,6 +302,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             }
         }
 
+        EPI_STAMP(0);            // per-element math + staging stores
         if constexpr (Q8 >= 0) {
             fp8_amax_commit(e.qo, q8_amax);
         } else if constexpr (STAGED) {
@@ -291,11 +310,13 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
             constexpr int EPV = 16 / (int)sizeof(T);               // elements per 16-byte chunk
             const int chunks_per_row = bn / EPV, bm = WM * MR * 32;
             __syncthreads();
+            EPI_STAMP(1);        // barrier: the staged tile is complete
             for (int cidx = threadIdx.x; cidx < bm * chunks_per_row; cidx += blockDim.x) {
                 const int r = cidx / chunks_per_row, c = cidx - r * chunks_per_row;
                 if (e.out && row_blk + r < M && col_blk + c * EPV < g.N)          // (fp8 path: out may be null, only q8 / q8t are kept)
                     *(u32x4_t*)(out + (long)(row_blk + r) * e.ldo + col_blk + c * EPV) = *(const u32x4_t*)(tile + r * bn + c * EPV);
             }
+            EPI_STAMP(2);        // copy-out loop (LDS reads + 16-byte stores issued)
         }
 
         if constexpr (Q8 >= 0) {
@@ -329,7 +350,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                         const int rsub = row_blk + (wm * MR + mi) * 32 + 4 * lh;
                         if (e.cs_mode == CS_SUM_XHAT) {
                             const bool cok = col < e.n_valid && col < g.N;
-                            const float mu = cok ? e.bn_mu[col] : 0.f, rstd = cok ? e.bn_rstd[col] : 0.f;
+                            const float mu = pf ? pf->mu[ni] : (cok ? e.bn_mu[col] : 0.f), rstd = pf ? pf->rstd[ni] : (cok ? e.bn_rstd[col] : 0.f);
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int row = rsub + (r & 3) + 8 * (r >> 2);
@@ -394,7 +415,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
                 }
             }
         }
+        EPI_STAMP(3);            // column sums
     }
+#undef EPI_STAMP
 }
 
 enum { TUNE_BIT_KC_PIPE = 1, TUNE_BIT_KS_W8 = 2, TUNE_BIT_NO_KS_GROUP = 4 };

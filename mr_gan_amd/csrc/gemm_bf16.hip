@@ -76,7 +76,7 @@ __device__ __forceinline__ void wait_groups(int n) {
 // (needs k-tile kt+1 landed one iteration early, so NS >= 4 to keep two k-tiles of LDS-DMA in flight).  Meant for
 // launches with <= 1 block per CU, where no second block hides the barrier -> ds_read -> MFMA latency chain.
 #ifdef MRGAN_STAMPS
-struct KcStamps { unsigned long long acc[6], prev; };      // make STAMPS=1: cycles per phase, summed over the block's tiles
+struct KcStamps { unsigned long long acc[6], prev, epi[5]; };      // make STAMPS=1: cycles per phase, summed over the block's tiles
 #define KC_STAMPS_PARAM , KcStamps& stamps_
 #define KC_STAMPS_ARG , stamps_
 #else
@@ -269,7 +269,11 @@ __device__ __forceinline__ void kc_tile(const GemmArgs& g, const int batch, cons
         STAMP(3);               // barrier after the main loop
         // the BM x BNT bf16 output tile is assembled at the start of the (now dead) ring, column-sum scratch behind it
         epilogue<__bf16, EPI, MR, NR, WM, true, VAR>(acc, g, batch, 0, tile_m, row_blk, col_blk, wm, wn, lane,
-                                                     (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf, htile);
+                                                     (float*)(lds + BM * BNT * 2), BNT, (__bf16*)lds, &pf, htile
+#ifdef MRGAN_STAMPS
+                                                     , stamps_.epi
+#endif
+                                                     );
         STAMP(4);               // epilogue (math, staging, copy-out issue, column sums)
         __syncthreads();        // the copy-out has read the staged tile: the ring may be refilled
         STAMP(5);
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
     const int ntn = (g.N + BNT - 1) / BNT, ntm = (g.M + BM - 1) / BM;
     const int ntiles = ntn * ntm * g.nbatch;
 #ifdef MRGAN_STAMPS
-    KcStamps stamps_ = {{0, 0, 0, 0, 0, 0}, __builtin_amdgcn_s_memtime()};
+    KcStamps stamps_ = {{0, 0, 0, 0, 0, 0}, __builtin_amdgcn_s_memtime(), {0, 0, 0, 0, 0}};
 #endif
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int tidx = xcd_tile(tl, ntiles);
@@ -301,7 +305,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kc_kernel(const GemmAr
     }
 #ifdef MRGAN_STAMPS
     if (g.e.slab && threadIdx.x == 0)
-        for (int i = 0; i < 6; ++i) ((unsigned long long*)g.e.slab)[(long)blockIdx.x * 8 + i] = stamps_.acc[i];
+    {
+        for (int i = 0; i < 6; ++i) ((unsigned long long*)g.e.slab)[(long)blockIdx.x * 12 + i] = stamps_.acc[i];
+        for (int i = 0; i < 4; ++i) ((unsigned long long*)g.e.slab)[(long)blockIdx.x * 12 + 6 + i] = stamps_.epi[i];
+    }
 #endif
 }
 
