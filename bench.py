@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
                     help="N > 1: payload of the gradient all-reduces (bf16 halves the bytes; a labelled, different numerical path)")
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 phase protocol (no all-reduce) on one GPU")
+    ap.add_argument("--dp-graph", action="store_true", help="N > 1: replay every phase range as a captured hipGraph (measured slower than eager launches)")
     args = ap.parse_args()
 
     import torch
@@ -250,7 +251,8 @@ def main():
     cfg.seed = 1
     cfg.rank, cfg.world = rank, world
     use_dp = world > 1 or args.force_dp
-    cfg.flags = dp_flags(exact=not args.local_stats) if use_dp else (0 if args.no_graph else E.FLAG_GRAPH)
+    cfg.flags = (dp_flags(exact=not args.local_stats, graph=args.dp_graph, grad_dtype=None if args.grad_dtype == "f32" else args.grad_dtype)
+                 if use_dp else (0 if args.no_graph else E.FLAG_GRAPH))
     stream = torch.cuda.Stream(dev)
     with torch.cuda.stream(stream):
         eng = E.Engine(cfg, dev)
@@ -461,7 +463,8 @@ def main():
                                   if args.hidden else "BASELINE configs[1]", args.rows, D, B, args.labeled_per_class),
                    "global_batch": B * world, "rows_per_gpu": B, "parallelism": "dp%d" % world if world > 1 else "single",
                    "batch_statistics": ("local_stats (per shard)" if args.local_stats else "synced over ranks") if world > 1 else "n/a",
-                   "launch": "eager phases + RCCL all-reduce (%s gradients)" % args.grad_dtype if world > 1 else ("eager" if args.no_graph else "hipGraph replay")},
+                   "launch": ("%s phases + RCCL all-reduce (%s gradients)" % ("hipGraph-replayed" if args.dp_graph else "eager", args.grad_dtype)) if use_dp
+                             else ("eager" if args.no_graph else "hipGraph replay")},
         "roofline": roofline,
         "train_metrics": {"mean_loss_lab": metrics[0] / timed_steps, "mean_loss_unl": metrics[1] / timed_steps,
                           "mean_train_err": metrics[2] / timed_steps, "mean_loss_gen": metrics[3] / timed_steps},

@@ -38,7 +38,15 @@ enum { MRGAN_NET_G = 0, MRGAN_NET_D = 1 };
 enum {
     MRGAN_FLAG_SYNC_STATS = 1,   /* batch statistics (BN, feature-matching moments) are exchanged between phases   */
     MRGAN_FLAG_FLAT_GRADS = 2,   /* gradients are reduced into the flat buffers; Adam runs as its own phase        */
-    MRGAN_FLAG_GRAPH      = 4    /* mrgan_train_pair replays a captured hipGraph (stream-mode arguments only)      */
+    MRGAN_FLAG_GRAPH      = 4,   /* stream-mode arguments only: mrgan_train_pair replays a captured hipGraph of the whole
+                                  * pair; with MRGAN_FLAG_FLAT_GRADS every phase range [first, last] passed to
+                                  * mrgan_disc_step / mrgan_gen_step is captured once and replayed (the kernels between two
+                                  * collectives of a data-parallel host)                                                */
+    MRGAN_FLAG_GRAD_BF16  = 8    /* with MRGAN_FLAG_FLAT_GRADS: the gradients travel as bfloat16.  The reduce phase writes
+                                  * MRGAN_REGION_GRAD_*_BF16 (rounded once from the fp32 sums) instead of the fp32 flat
+                                  * buffers and the Adam phase reads them back: the host all-reduces those regions in place,
+                                  * nothing is cast or allocated per step.  The four fp32 scalars behind the fp32 buffers
+                                  * (MRGAN_REGION_TAIL_*) still travel in fp32.  A labelled, different numerical path.      */
 };
 
 /* Hyper-parameters are literals inside mr_gan() in the reference (mr_gan.py:77-79, :111-128, :165);
@@ -175,7 +183,11 @@ enum {
     MRGAN_REGION_BN_BWD = 2,     /* after G_BWD : [2][N1p]  sum dy, sum dy*xhat                                  */
     MRGAN_REGION_GRAD_D = 3,     /* after D_MAIN: flat padded gradients of the 12 D tensors + 4 scalars          */
     MRGAN_REGION_GRAD_G = 4,     /* after G_TAIL: flat padded gradients of the 8 G tensors + 4 scalars           */
-    MRGAN_REGION_WORKSPACE = 5
+    MRGAN_REGION_WORKSPACE = 5,
+    MRGAN_REGION_GRAD_D_BF16 = 6, /* MRGAN_FLAG_GRAD_BF16: bfloat16 [n] flat padded gradients of the D tensors (same element order) */
+    MRGAN_REGION_GRAD_G_BF16 = 7, /* ... of the G tensors                                                                    */
+    MRGAN_REGION_TAIL_D = 8,      /* the 4 fp32 scalars at the end of MRGAN_REGION_GRAD_D (loss sums of the D sub-step)        */
+    MRGAN_REGION_TAIL_G = 9
 };
 int mrgan_region(mrgan_handle* h, int region, void** ptr_dev, size_t* bytes);
 

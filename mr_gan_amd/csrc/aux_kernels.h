@@ -92,13 +92,15 @@ struct FmArgs {
 int launch_fm(int bf16, const FmArgs& a, hipStream_t s);
 
 // ---- collapse per-row-tile partial sums to one row (data-parallel statistic exchange) ----
-int launch_colsum_finalize(const float* part1, const float* part2, int npart, int ld, int n, float* out /* [2][n] */, hipStream_t s);
+int launch_colsum_finalize(const float* part1, const float* part2, int npart, int ld, int n, float* out /* [nseg][2][n] */, hipStream_t s,
+                           int nseg = 1 /* segments: partial rows npart * ld floats apart */);
 
 // ---- multi-tensor Adam (Keras 2.0.9 formula, mr_gan.py:165-167) ----
 struct AdamTile {
     float* p; float* m; float* v;
     const float* g; int nslab; long slab_stride;       // gradient = sum of nslab slabs
     float* flat;                                       // flat gradient buffer (tile origin)
+    __bf16* flat16;                                    // MRGAN_FLAG_GRAD_BF16: bfloat16 flat gradient buffer instead (null otherwise)
     __bf16* w16; __bf16* wt16;                         // bf16 copies [K][N] and [N][K] (null for fp32 / 1-D)
     unsigned char* w8; unsigned char* w8t; Fp8Slot* w8_slot;      // fp8 mode: e4m3 copies of the bf16 values (same tile origins)
     int ld, ldt;                                       // row pitch of p/m/v/g/w16 ; of wt16

@@ -566,11 +566,12 @@ __global__ __launch_bounds__(256) void fm_kernel(const FmArgs a) {
 }
 
 // two sets of per-row-tile partial sums -> two rows of `out` (out[0..n) and out[n..2n)); blockIdx.y picks the set
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part1, const float* part2, int npart, int ld, int n, float* out) {
+// blockIdx.z: independent segments (their partial rows follow each other, `seg_part` floats apart; their results 2 n apart)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part1, const float* part2, int npart, int ld, int n, float* out, long seg_part) {
     __shared__ float scr[16][CB], res[CB];
     const int col0 = blockIdx.x * CB;
-    fold_partials(blockIdx.y ? part2 : part1, npart, ld, col0, n, scr, res);
-    if (threadIdx.x < CB && col0 + threadIdx.x < n) out[(long)blockIdx.y * n + col0 + threadIdx.x] = res[threadIdx.x];
+    fold_partials((blockIdx.y ? part2 : part1) + (long)blockIdx.z * seg_part, npart, ld, col0, n, scr, res);
+    if (threadIdx.x < CB && col0 + threadIdx.x < n) out[((long)blockIdx.z * 2 + blockIdx.y) * n + col0 + threadIdx.x] = res[threadIdx.x];
 }
 
 // =========================================================================================
@@ -592,6 +593,16 @@ __device__ __forceinline__ f32x4 adam_sum_slabs(const float* g, long stride, int
     }
     for (; sl < nslab; sl += step) g0 += *(const f32x4*)(g + (long)sl * stride);
     return (g0 + g1) + (g2 + g3);
+}
+
+// the flat gradient of one four-element group: fp32, or bfloat16 when the gradients travel as bfloat16 (MRGAN_FLAG_GRAD_BF16)
+__device__ __forceinline__ f32x4 flat_load(const AdamTile& tile, long off) {
+    if (tile.flat16) { const bf16x4 v = *(const bf16x4*)(tile.flat16 + off); return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+    return *(const f32x4*)(tile.flat + off);
+}
+__device__ __forceinline__ void flat_store(const AdamTile& tile, long off, const f32x4 g) {
+    if (tile.flat16) *(bf16x4*)(tile.flat16 + off) = (bf16x4){(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
+    else *(f32x4*)(tile.flat + off) = g;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
@@ -639,7 +650,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         const long off = (long)r * tile.ld + tc;
         f32x4 g = {0.f, 0.f, 0.f, 0.f}, pn = g;
         if (valid) {
-            if (a.mode == ADAM_FROM_FLAT) { if (sl0 == 0) g = *(const f32x4*)(tile.flat + off); }
+            if (a.mode == ADAM_FROM_FLAT) { if (sl0 == 0) g = flat_load(tile, off); }
             else g = adam_sum_slabs(tile.g + off, tile.slab_stride, sl0, lanes, tile.nslab);
         }
         *(f32x4*)(tl + t * 4) = g;                        // combine the slab lanes
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         if (sl0 == 0)
             for (int k = 1; k < lanes; ++k) g += *(const f32x4*)(tl + (t + QL * k) * 4);
         if (valid && sl0 == 0) {
-            if (a.mode == ADAM_REDUCE_ONLY) *(f32x4*)(tile.flat + off) = g;
+            if (a.mode == ADAM_REDUCE_ONLY) flat_store(tile, off, g);
             else { pn = *(const f32x4*)(tile.p + off); update(g, *(const f32x4*)(tile.m + off), *(const f32x4*)(tile.v + off), pn, off); }
         }
     } else {
@@ -664,7 +675,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
             off[u] = (long)r * tile.ld + tc;
             g[u] = m[u] = v[u] = pn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (valid[u]) {
-                g[u] = a.mode == ADAM_FROM_FLAT ? *(const f32x4*)(tile.flat + off[u]) : adam_sum_slabs(tile.g + off[u], tile.slab_stride, 0, 1, tile.nslab);
+                g[u] = a.mode == ADAM_FROM_FLAT ? flat_load(tile, off[u]) : adam_sum_slabs(tile.g + off[u], tile.slab_stride, 0, 1, tile.nslab);
                 if (a.mode != ADAM_REDUCE_ONLY) { m[u] = *(const f32x4*)(tile.m + off[u]); v[u] = *(const f32x4*)(tile.v + off[u]); pn[u] = *(const f32x4*)(tile.p + off[u]); }
             }
         }
@@ -672,7 +683,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         for (int u = 0; u < 4; ++u) {
             const int r = (t >> 4) + 16 * u;
             if (valid[u]) {
-                if (a.mode == ADAM_REDUCE_ONLY) *(f32x4*)(tile.flat + off[u]) = g[u];
+                if (a.mode == ADAM_REDUCE_ONLY) flat_store(tile, off[u], g[u]);
                 else update(g[u], m[u], v[u], pn[u], off[u]);
             }
             if (tile.wt16) {
@@ -829,9 +840,9 @@ int launch_fm(int bf16, const FmArgs& a, hipStream_t s) {
     RET_LAUNCH;
 }
 
-int launch_colsum_finalize(const float* part1, const float* part2, int npart, int ld, int n, float* out, hipStream_t s) {
+int launch_colsum_finalize(const float* part1, const float* part2, int npart, int ld, int n, float* out, hipStream_t s, int nseg) {
     if (n % 4) return -3;
-    MRGAN_LAUNCH(colsum_finalize_kernel, dim3(ceil_div(n, CB), 2), dim3(256), 0, s, part1, part2, npart, ld, n, out);
+    MRGAN_LAUNCH(colsum_finalize_kernel, dim3(ceil_div(n, CB), 2, nseg), dim3(256), 0, s, part1, part2, npart, ld, n, out, (long)npart * ld);
     RET_LAUNCH;
 }
 

@@ -56,6 +56,7 @@ struct Tensor {                // one trainable tensor (padded fp32 master + Ada
     float *p, *m, *v;
     __bf16 *w16, *wt16;
     float* flat;               // position inside the flat gradient buffer
+    __bf16* flat16;            // ... inside the bfloat16 one (MRGAN_FLAG_GRAD_BF16)
     const float* g; int nslab; long slab_stride;      // fused-mode gradient source
 };
 
@@ -106,6 +107,7 @@ struct mrgan_handle {
     float* accum;                         // [4]
     int* err_count;
     float *flat_d, *flat_g; size_t flat_d_n, flat_g_n;
+    __bf16 *flat16_d, *flat16_g;          // MRGAN_FLAG_GRAD_BF16
     float *r_bn_stats, *r_fm, *r_bn_bwd;
 
     // activations (T = float | __bf16)
@@ -142,6 +144,10 @@ struct mrgan_handle {
 
     // graph replay of (D step, G step)
     hipGraphExec_t graph_exec; bool graph_ready; int graph_cur; mrgan_disc_args graph_d; mrgan_gen_args graph_g;
+    // graph replay of phase ranges (data-parallel hosts: the kernels between two collectives), see phase_graph_run
+    struct PhaseState { int cur, pair_gen, gen_ready, real_staged, xbase, gen_seg, fp8_kind; };
+    struct PhaseGraph { int kind, p0, p1; PhaseState pre, post; mrgan_disc_args d; mrgan_gen_args g; hipGraphExec_t exec; };
+    std::vector<PhaseGraph> phase_graphs;
 };
 
 namespace {
@@ -218,6 +224,7 @@ int validate(const mrgan_config& c) {
     if (c.world < 1 || c.rank < 0 || c.rank >= c.world) return fail(-1, "bad rank/world");
     if (c.world > 1 && (c.batch % 4) != 0) return fail(-1, "data-parallel shards need batch %% 4 == 0 (noise row groups)");
     if (c.world > 1 && (c.flags & (MRGAN_FLAG_FLAT_GRADS)) == 0) return fail(-1, "world > 1 requires MRGAN_FLAG_FLAT_GRADS");
+    if ((c.flags & MRGAN_FLAG_GRAD_BF16) && !(c.flags & MRGAN_FLAG_FLAT_GRADS)) return fail(-1, "MRGAN_FLAG_GRAD_BF16 requires MRGAN_FLAG_FLAT_GRADS");
     for (int i = 0; i < 5; ++i) if (c.d_hidden[i] < 1) return fail(-1, "bad d_hidden");
     if (c.g_hidden[0] < 1 || c.g_hidden[1] < 1 || c.noise_size < 1) return fail(-1, "bad generator sizes");
     return 0;
@@ -258,7 +265,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
         t.p = a.take<float>(n); t.m = a.take<float>(n); t.v = a.take<float>(n);
         t.w16 = t.wt16 = nullptr;
         if (copies && h->bf16) { t.w16 = a.take<__bf16>(n); t.wt16 = a.take<__bf16>(n); }
-        t.g = nullptr; t.nslab = 0; t.slab_stride = 0; t.flat = nullptr;
+        t.g = nullptr; t.nslab = 0; t.slab_stride = 0; t.flat = nullptr; t.flat16 = nullptr;
     };
     // generator: W1 b1 gamma beta W2 b2 W3 b3
     const int gW[3] = {0, 4, 6}, gb[3] = {1, 5, 7};
@@ -277,15 +284,17 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
         h->d[l] = Dense{K, N, Kp, Np, l < 5 ? ACT_RELU : ACT_LINEAR, &h->dt[2 * l], &h->dt[2 * l + 1], nullptr, 1};
     }
     // flat gradient buffers (padded layout, Keras order) + 4 scalars
-    auto flat = [&](std::vector<Tensor>& ts, float*& buf, size_t& n) {
+    const bool g16 = (c.flags & MRGAN_FLAG_GRAD_BF16) != 0;
+    auto flat = [&](std::vector<Tensor>& ts, float*& buf, __bf16*& buf16, size_t& n) {
         n = 0;
         for (auto& t : ts) n += (size_t)t.prow * t.pcol;
         buf = a.take<float>(n + 4);
+        buf16 = g16 ? a.take<__bf16>(n) : nullptr;
         size_t o = 0;
-        for (auto& t : ts) { t.flat = buf ? buf + o : nullptr; o += (size_t)t.prow * t.pcol; }
+        for (auto& t : ts) { t.flat = buf ? buf + o : nullptr; t.flat16 = buf16 ? buf16 + o : nullptr; o += (size_t)t.prow * t.pcol; }
     };
-    flat(h->gt, h->flat_g, h->flat_g_n);
-    flat(h->dt, h->flat_d, h->flat_d_n);
+    flat(h->gt, h->flat_g, h->flat16_g, h->flat_g_n);
+    flat(h->dt, h->flat_d, h->flat16_d, h->flat_d_n);
     const int N1p = h->g[0].Np;
     h->r_bn_stats = a.take<float>(4 * N1p);                 // [segment][sum h | sum h^2][N1p]
     h->r_fm = a.take<float>(2 * h->Fp);
@@ -348,16 +357,19 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     int tiles_d = 0, tiles_g = 0;
     for (int l = 0; l < 5; ++l) tiles_d += dw_tiles(h->d[l]);
     for (int l = 0; l < 3; ++l) tiles_g += dw_tiles(h->g[l]);
+    // (256 x 128 output tiles with one 8-wave block per CU were tried for the discriminator's launch in round 3: 25 % fewer staged
+    //  bytes per flop, but 54.5 us against 47.5 us with two- and three-stage rings -- 200 blocks leave a fifth of the CUs idle)
+    const int splits_d = choose_splits(tiles_d, 2 * S + B), splits_g = choose_splits(tiles_g, B);
     for (int l = 0; l < 5; ++l) {
         Dense& L = h->d[l];
         // fp8: one product per layer over all 3 S rows; only a layer with too few 128 x 128 output tiles to fill the chip
         // (the first layer of a wide stack) splits its reduction
-        L.splits = h->fp8 ? fp8_dw_splits(dw_tiles(L), 3 * S) : choose_splits(tiles_d, 2 * S + B);
+        L.splits = h->fp8 ? fp8_dw_splits(dw_tiles(L), 3 * S) : splits_d;
         L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     for (int l = 0; l < 3; ++l) {
         Dense& L = h->g[l];
-        L.splits = (h->fp8 && l == 1) ? 1 : choose_splits(tiles_g, B);       // fp8: G2's weight gradient is one fp8 product
+        L.splits = (h->fp8 && l == 1) ? 1 : splits_g;       // fp8: G2's weight gradient is one fp8 product
         L.slabs = a.take<float>((size_t)L.splits * L.Kp * L.Np);
     }
     // ---- fused-mode gradient sources ----------------------------------------------------------------
@@ -408,7 +420,7 @@ int upload_tiles(mrgan_handle* h, std::vector<Tensor>& ts, AdamTile* dev, int n,
                 const long off = (long)r0 * t.pcol + c0;
                 a.p = t.p + off; a.m = t.m + off; a.v = t.v + off;
                 a.g = t.g + off; a.nslab = t.nslab; a.slab_stride = t.slab_stride;
-                a.flat = t.flat + off;
+                a.flat = t.flat + off; a.flat16 = t.flat16 ? t.flat16 + off : nullptr;
                 a.w16 = t.w16 ? t.w16 + off : nullptr;
                 a.wt16 = t.wt16 ? t.wt16 + (long)c0 * t.prow + r0 : nullptr;
                 a.w8 = a.w8t = nullptr; a.w8_slot = nullptr;
@@ -805,11 +817,8 @@ int gen_fwd_head(mrgan_handle* h, int nb, hipStream_t s) {
     CHK(dense_fwd(h, h->g[0], h->zbuf, h->B, nb, h->h1, ACT_SOFTPLUS, 0.f, 0, 0, nullptr, 0, CS_SUM_SQ, h->cs_bn1, h->cs_bn2,
                   true, s));
     if (h->sync_stats) {
-        const int n = h->g[0].Np;
-        for (int sg = 0; sg < nb; ++sg) {
-            const size_t o = (size_t)sg * h->tiles_m * n;
-            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn1 + o, h->cs_bn2 + o, h->tiles_m, n, n, h->r_bn_stats + (size_t)sg * 2 * n, s));
-        }
+        const int n = h->g[0].Np;          // both segments of a paired forward in one launch
+        PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_bn1, h->cs_bn2, h->tiles_m, n, n, h->r_bn_stats, s, nb));
     }
     return 0;
 }
@@ -1254,6 +1263,60 @@ int eval_rows(mrgan_handle* h, const float* x, const int32_t* idx, long ld, cons
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Phase-range graphs.  A data-parallel host calls the sub-steps phase by phase, with its collectives in between
+// (mr_gan_amd/dist.py); launched eagerly those 22 kernels cost 7 % more than the whole-pair graph of mrgan_train_pair (launch
+// gaps).  With MRGAN_FLAG_GRAPH every phase range [p0, p1] of a stream-mode sub-step is captured once and replayed: kernel
+// arguments never change between steps (DevState slots, device-side batch counter), and the host-side state a phase reads and
+// leaves behind (slot parity, the pairing flags, the generator view) is part of the cache key / restored from the snapshot
+// taken when the range was captured.
+// ---------------------------------------------------------------------------------------------------
+mrgan_handle::PhaseState phase_snap(const mrgan_handle* h) {
+    return mrgan_handle::PhaseState{h->cur, h->pair_gen, h->gen_ready, h->real_staged, h->xbase, h->gen_seg, h->fp8_kind};
+}
+void phase_restore(mrgan_handle* h, const mrgan_handle::PhaseState& st) {
+    set_gen_view(h, st.gen_seg);
+    h->cur = st.cur; h->pair_gen = st.pair_gen; h->gen_ready = st.gen_ready; h->real_staged = st.real_staged;
+    h->xbase = st.xbase; h->fp8_kind = st.fp8_kind;
+}
+void phase_graphs_clear(mrgan_handle* h) {
+    for (auto& g : h->phase_graphs) hipGraphExecDestroy(g.exec);
+    h->phase_graphs.clear();
+}
+// kind 0: disc phases of `d`; kind 1: gen phases of `g`.  Returns 1 when the range was not graphed (caller runs it eagerly).
+template <typename Run>
+int phase_graph_run(mrgan_handle* h, int kind, int p0, int p1, const mrgan_disc_args* d, const mrgan_gen_args* g, hipStream_t s, Run run) {
+    const bool want = (h->cfg.flags & MRGAN_FLAG_GRAPH) && h->flat_grads && !h->prof && !h->pair_g &&
+                      (kind == 0 ? d->stream_mode : g->stream_mode) && (!h->fp8 || (h->fp8_cal[0] == 1 && h->fp8_cal[1] == 1));
+    if (!want) return 1;
+    const mrgan_handle::PhaseState pre = phase_snap(h);
+    for (auto& pg : h->phase_graphs) {
+        if (pg.kind != kind || pg.p0 != p0 || pg.p1 != p1 || memcmp(&pg.pre, &pre, sizeof pre) != 0) continue;
+        if (kind == 0 ? memcmp(&pg.d, d, sizeof *d) != 0 : memcmp(&pg.g, g, sizeof *g) != 0) continue;
+        phase_restore(h, pg.post);
+        HIPCHK(hipGraphLaunch(pg.exec, s));
+        return 0;
+    }
+    if (h->phase_graphs.size() >= 64) phase_graphs_clear(h);           // (argument pointers keep changing: start over)
+    mrgan_handle::PhaseGraph pg;
+    memset(&pg, 0, sizeof pg);
+    pg.kind = kind; pg.p0 = p0; pg.p1 = p1; pg.pre = pre;
+    if (kind == 0) pg.d = *d; else pg.g = *g;
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int r = run();
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (r) { if (graph) hipGraphDestroy(graph); return r; }
+    if (e != hipSuccess) return fail(-10, "hipStreamEndCapture (phase range): %s", hipGetErrorString(e));
+    const hipError_t e2 = hipGraphInstantiate(&pg.exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e2 != hipSuccess) return fail(-10, "hipGraphInstantiate (phase range): %s", hipGetErrorString(e2));
+    pg.post = phase_snap(h);
+    h->phase_graphs.push_back(pg);
+    HIPCHK(hipGraphLaunch(pg.exec, s));
+    return 0;
+}
+
 Tensor* find_tensor(mrgan_handle* h, int net, int idx) {
     std::vector<Tensor>& ts = net == MRGAN_NET_G ? h->gt : h->dt;
     if (net != MRGAN_NET_G && net != MRGAN_NET_D) return nullptr;
@@ -1355,6 +1418,7 @@ int mrgan_create(const mrgan_config* cfg, void* workspace, size_t bytes, mrgan_s
 int mrgan_destroy(mrgan_handle* h) {
     if (!h) return 0;
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    phase_graphs_clear(h);
     if (h->own_ws && h->ws) hipFree(h->ws);
     delete h;
     return 0;
@@ -1398,6 +1462,7 @@ int mrgan_get_weights(mrgan_handle* h, int net, int idx, float* dst, mrgan_strea
 int mrgan_get_slot(mrgan_handle* h, int net, int idx, int which, float* dst, mrgan_stream stream) {
     Tensor* t = find_tensor(h, net, idx);
     if (!t || !dst || which < 0 || which > 2) return fail(-1, "get_slot: bad argument");
+    if (which == 2 && t->flat16) return fail(-3, "get_slot: the flat gradients of this handle are bfloat16 (MRGAN_REGION_GRAD_*_BF16)");
     const float* src = which == 0 ? t->m : which == 1 ? t->v : t->flat;
     HIPCHK(hipMemcpy2DAsync(dst, sizeof(float) * t->cols, src, sizeof(float) * t->pcol, sizeof(float) * t->cols, t->rows,
                             hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1446,7 +1511,9 @@ int mrgan_disc_step(mrgan_handle* h, const mrgan_disc_args* a, int p0, int p1, f
         }
         h->fp8_cal[0] = 1;
     }
-    for (int p = p0; p <= p1; ++p) { r = disc_phase(h, a, p, s); if (r) return r; }
+    r = phase_graph_run(h, 0, p0, p1, a, nullptr, s, [&]() { int rr = 0; for (int p = p0; p <= p1 && !rr; ++p) rr = disc_phase(h, a, p, s); return rr; });
+    if (r < 0) return r;
+    if (r == 1) for (int p = p0; p <= p1; ++p) { r = disc_phase(h, a, p, s); if (r) return r; }
     if (out3) {
         HIPCHK(hipMemcpyAsync(out3, h->step_out, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1473,7 +1540,9 @@ int mrgan_gen_step(mrgan_handle* h, const mrgan_gen_args* a, int p0, int p1, flo
         HIPCHK(hipMemcpyAsync(h->accum, h->accum_save, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
         h->fp8_cal[1] = 1;
     }
-    for (int p = p0; p <= p1; ++p) { r = gen_phase(h, a, p, s); if (r) return r; }
+    r = phase_graph_run(h, 1, p0, p1, nullptr, a, s, [&]() { int rr = 0; for (int p = p0; p <= p1 && !rr; ++p) rr = gen_phase(h, a, p, s); return rr; });
+    if (r < 0) return r;
+    if (r == 1) for (int p = p0; p <= p1; ++p) { r = gen_phase(h, a, p, s); if (r) return r; }
     if (out1) {
         HIPCHK(hipMemcpyAsync(out1, h->step_out + 3, sizeof(float), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1578,6 +1647,7 @@ int mrgan_train_pair(mrgan_handle* h, const mrgan_disc_args* d, const mrgan_gen_
 int mrgan_set_tuning(mrgan_handle* h, int knob, int value) {
     if (!h) return fail(-1, "null handle");
     if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_ready = false; }   // launches change
+    phase_graphs_clear(h);
     switch (knob) {
         case MRGAN_TUNE_CHAIN: h->use_chain = value != 0 && h->chain_ok; break;
         case MRGAN_TUNE_KC_CFG: h->tune_kc_cfg = value; break;
@@ -1606,6 +1676,14 @@ int mrgan_region(mrgan_handle* h, int region, void** ptr, size_t* bytes) {
         case MRGAN_REGION_GRAD_D: *ptr = h->flat_d; *bytes = (h->flat_d_n + 4) * 4; break;
         case MRGAN_REGION_GRAD_G: *ptr = h->flat_g; *bytes = (h->flat_g_n + 4) * 4; break;
         case MRGAN_REGION_WORKSPACE: *ptr = h->ws; *bytes = h->ws_bytes; break;
+        case MRGAN_REGION_GRAD_D_BF16: case MRGAN_REGION_GRAD_G_BF16: {
+            if (!h->flat16_d) return fail(-3, "the bfloat16 gradient regions exist with MRGAN_FLAG_GRAD_BF16 only");
+            const bool d = region == MRGAN_REGION_GRAD_D_BF16;
+            *ptr = d ? h->flat16_d : h->flat16_g; *bytes = (d ? h->flat_d_n : h->flat_g_n) * 2;
+            break;
+        }
+        case MRGAN_REGION_TAIL_D: *ptr = h->flat_d + h->flat_d_n; *bytes = 16; break;
+        case MRGAN_REGION_TAIL_G: *ptr = h->flat_g + h->flat_g_n; *bytes = 16; break;
         default: return fail(-1, "unknown region %d", region);
     }
     return 0;
@@ -1678,6 +1756,8 @@ int mrgan_debug_noise(mrgan_handle* h, uint32_t site, uint32_t seg, uint32_t ste
 
 int mrgan_debug_ablate(mrgan_handle* h, int bits) {
     if (!h) return fail(-1, "null handle");
+    if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_ready = false; }
+    phase_graphs_clear(h);
     h->ablate = bits;
     return 0;
 }

@@ -57,7 +57,8 @@ class DataParallel(object):
     """grad_dtype: None (default) all-reduces the flat gradient buffers in fp32 -- replicas then reproduce the one-GPU step up
     to summation order; 'bf16' sends them as bfloat16 (half the bytes on the xGMI links: 2.5 MB instead of 5.1 MB for the
     discriminator at D = 512; the four scalars at the tail stay fp32) at the price of an 8-bit mantissa per addend -- a
-    different, labelled numerical path.  The small statistic regions always travel in fp32."""
+    different, labelled numerical path.  It needs a backend built with dp_flags(grad_dtype='bf16'): the engine then writes and
+    reads the bfloat16 regions itself.  The small statistic regions always travel in fp32."""
 
     def __init__(self, backend, exact=True, group=None, grad_dtype=None):
         self.backend = backend
@@ -69,17 +70,14 @@ class DataParallel(object):
     def _allreduce(self, which):
         if self.world <= 1:
             return
-        r = self.backend.region(which)
         if self.grad_dtype == 'bf16' and which in (E.REGION_GRAD_D, E.REGION_GRAD_G):
-            import torch
-            body, tail = r[:-4], r[-4:].clone()
-            g16 = body.to(torch.bfloat16)
-            dist.all_reduce(g16, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
-            body.copy_(g16)
-            r[-4:].copy_(tail)
+            # the library wrote the gradients as bfloat16 (FLAG_GRAD_BF16) and reads them back from the same region: reduced in
+            # place, no cast, no allocation; the four loss scalars travel on in fp32
+            d = which == E.REGION_GRAD_D
+            dist.all_reduce(self.backend.region(E.REGION_GRAD_D_BF16 if d else E.REGION_GRAD_G_BF16), op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.backend.region(E.REGION_TAIL_D if d else E.REGION_TAIL_G), op=dist.ReduceOp.SUM, group=self.group)
         else:
-            dist.all_reduce(r, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.backend.region(which), op=dist.ReduceOp.SUM, group=self.group)
 
     def _calibrate(self, kind, run_pass):
         """fp8 engines: the first sub-step of a kind is preceded by dry passes (forward + backward phases WITH the statistic
@@ -163,5 +161,9 @@ class DataParallel(object):
         self.gen_step(gargs, stats_done=paired)
 
 
-def dp_flags(exact=True):
-    return E.FLAG_FLAT_GRADS | (E.FLAG_SYNC_STATS if exact else 0)
+def dp_flags(exact=True, graph=False, grad_dtype=None):
+    """handle flags of a data-parallel rank.  graph=True: the kernels of every phase range are replayed as captured hipGraphs
+    (stream-mode arguments; the collectives stay between the ranges; measured SLOWER than eager launches on one GPU, see
+    DESIGN.md section 6).  grad_dtype='bf16': the gradients travel as bfloat16 (DataParallel(grad_dtype='bf16'))."""
+    return (E.FLAG_FLAT_GRADS | (E.FLAG_SYNC_STATS if exact else 0) | (E.FLAG_GRAPH if graph else 0) |
+            (E.FLAG_GRAD_BF16 if grad_dtype == 'bf16' else 0))

@@ -15,11 +15,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmrgan_hip.so")
 
 F32, BF16, FP8 = 0, 1, 2
 NET_G, NET_D = 0, 1
-FLAG_SYNC_STATS, FLAG_FLAT_GRADS, FLAG_GRAPH = 1, 2, 4
+FLAG_SYNC_STATS, FLAG_FLAT_GRADS, FLAG_GRAPH, FLAG_GRAD_BF16 = 1, 2, 4, 8
 D_GEN, D_MAIN, D_ADAM = 0, 1, 2
 G_GEN, G_FEAT, G_BWD, G_TAIL, G_ADAM = 0, 1, 2, 3, 4
 TUNE_CHAIN, TUNE_KC_CFG, TUNE_KC_PIPE, TUNE_KS_W8, TUNE_KS_GROUP, TUNE_PAIR_GEN = range(6)
 REGION_BN_STATS, REGION_FM_MOMENTS, REGION_BN_BWD, REGION_GRAD_D, REGION_GRAD_G, REGION_WORKSPACE = range(6)
+REGION_GRAD_D_BF16, REGION_GRAD_G_BF16, REGION_TAIL_D, REGION_TAIL_G = 6, 7, 8, 9
 
 EXPORTS = [
     "mrgan_default_config", "mrgan_workspace_bytes", "mrgan_create", "mrgan_destroy", "mrgan_last_error",
@@ -319,11 +320,12 @@ class Engine(object):
         return out
 
     def region(self, which):
-        """fp32 torch view of a workspace region (aliases library memory: used for all-reduce)."""
+        """torch view of a workspace region (aliases library memory: used for all-reduce): fp32, bfloat16 for the
+        REGION_GRAD_*_BF16 regions of a FLAG_GRAD_BF16 handle."""
         p, n = C.c_void_p(), C.c_size_t()
         _check(self.lib.mrgan_region(self.handle, which, C.byref(p), C.byref(n)))
         off = p.value - self.workspace.data_ptr()
-        return self.workspace[off:off + n.value].view(torch.float32)
+        return self.workspace[off:off + n.value].view(torch.bfloat16 if which in (REGION_GRAD_D_BF16, REGION_GRAD_G_BF16) else torch.float32)
 
     def debug_ablate(self, bits):
         _check(self.lib.mrgan_debug_ablate(self.handle, int(bits)))

@@ -52,10 +52,29 @@ class OraclePhases(object):
             E.REGION_GRAD_D: torch.zeros(sum(p.size for p in d) + 4, dtype=torch.float64),
             E.REGION_GRAD_G: torch.zeros(sum(p.size for p in g) + 4, dtype=torch.float64),
         }
+        self.bf16 = False           # FLAG_GRAD_BF16: the reduce phases write bfloat16 regions (+ fp32 tails), the Adam phases read them
         self.last = None
 
     def region(self, which):
         return self.regions[which]
+
+    def _publish(self, which):
+        """what the engine's reduce phase does with MRGAN_FLAG_GRAD_BF16: gradients rounded once to bfloat16, the four scalars fp32"""
+        E = self.E
+        if not self.bf16:
+            return
+        d = which == E.REGION_GRAD_D
+        v = self.regions[which]
+        self.regions[E.REGION_GRAD_D_BF16 if d else E.REGION_GRAD_G_BF16] = v[:-4].to(torch.bfloat16)
+        self.regions[E.REGION_TAIL_D if d else E.REGION_TAIL_G] = v[-4:].float()
+
+    def _collect(self, which):
+        E = self.E
+        if not self.bf16:
+            return self.regions[which].numpy()
+        d = which == E.REGION_GRAD_D
+        body = self.regions[E.REGION_GRAD_D_BF16 if d else E.REGION_GRAD_G_BF16].double().numpy()
+        return np.concatenate([body, self.regions[E.REGION_TAIL_D if d else E.REGION_TAIL_G].double().numpy()])
 
     # ---- generator pieces with externally supplied (global) batch statistics ----
     def _gen_head(self, z):
@@ -100,8 +119,9 @@ class OraclePhases(object):
                 grads = g_ if grads is None else [x + y for x, y in zip(grads, g_)]
             tail = np.array([ll, lu, err, 0.0]) / self.world
             self.regions[E.REGION_GRAD_D][:] = torch.from_numpy(np.concatenate([_flat(grads), tail]))
+            self._publish(E.REGION_GRAD_D)
         elif phase == E.D_ADAM:
-            v = self.regions[E.REGION_GRAD_D].numpy()
+            v = self._collect(E.REGION_GRAD_D)
             orc.adam.apply(orc.d, _unflat(v[:-4], orc.d), 'd')
             self.last = tuple(v[-4:-1])
 
@@ -142,8 +162,9 @@ class OraclePhases(object):
             loc_dgamma, loc_dbeta = (self.dhbn * self.xhat).sum(0), self.dhbn.sum(0)
             grads = [self.z.T @ dpre1, dpre1.sum(0), loc_dgamma, loc_dbeta, self.dW2, self.db2, self.dW3, self.db3]
             self.regions[E.REGION_GRAD_G][:] = torch.from_numpy(np.concatenate([_flat(grads), np.zeros(4)]))
+            self._publish(E.REGION_GRAD_G)
         elif phase == E.G_ADAM:
-            v = self.regions[E.REGION_GRAD_G].numpy()
+            v = self._collect(E.REGION_GRAD_G)
             orc.adam.apply(orc.g, _unflat(v[:-4], orc.g), 'g')
             self.last = self.loss
 
@@ -166,8 +187,7 @@ def _worker(rank, world, port, exact, q, sorted_labels=False, grad_dtype=None):
     case = _case(sorted_labels)
     h = B // world
     backend = OraclePhases(case.g0, case.d0, world, exact)
-    if grad_dtype:                                        # the stand-in's regions are fp64; bf16 needs an fp32 carrier
-        backend.regions = {k: v.float() for k, v in backend.regions.items()}
+    backend.bf16 = grad_dtype == 'bf16'
     dp = DataParallel(backend, exact=exact, grad_dtype=grad_dtype)
     res = []
     it = 0

@@ -653,6 +653,57 @@ def test_two_rank_emulation_equals_full_batch():
         e.close()
 
 
+def test_two_rank_emulation_with_bf16_gradient_payload():
+    """MRGAN_FLAG_GRAD_BF16: the reduce phases write the gradients as bfloat16 regions, the host sums those in place (here: a
+    host-side add of two rank handles, rounded once like a bf16 all-reduce), the Adam phases read them back -- no fp32 flat buffer
+    travels.  Replicas stay bit-identical, the first sub-step's losses are the full-batch ones, and the weights are the fp32
+    exchange's up to the bf16 rounding of the gradients (a labelled, different numerical path)."""
+    from mr_gan_amd import engine as E
+    B, D = 64, 32
+    case = Case(D=D, B=B, steps=2, device_z=True)
+    ref = case.run_oracle()
+    flags = E.FLAG_FLAT_GRADS | E.FLAG_SYNC_STATS | E.FLAG_GRAD_BF16
+    ranks = [_engine(D, B // 2, 0, flags=flags, rank=r, world=2) for r in range(2)]
+    for e in ranks:
+        _load(e, case)
+    with pytest.raises(E.MrganError, match="bfloat16"):
+        ranks[0].get_slot(E.NET_D, 2)
+
+    def allreduce(region):
+        for reg in ({E.REGION_GRAD_D: (E.REGION_GRAD_D_BF16, E.REGION_TAIL_D), E.REGION_GRAD_G: (E.REGION_GRAD_G_BF16, E.REGION_TAIL_G)}.get(region, (region,))):
+            views = [e.region(reg) for e in ranks]
+            tot = (views[0].float() + views[1].float()).to(views[0].dtype)
+            for v in views:
+                v.copy_(tot)
+
+    h = B // 2
+    for t in range(case.steps):
+        da = [E.Engine.disc_args(_t(case.x_lab[t][r * h:(r + 1) * h]), _t(case.labels[t][r * h:(r + 1) * h], torch.int32),
+                                 _t(case.x_unl[t][r * h:(r + 1) * h])) for r in range(2)]
+        for ph, reg in ((E.D_GEN, E.REGION_BN_STATS), (E.D_MAIN, E.REGION_GRAD_D)):
+            for e, a in zip(ranks, da):
+                e.disc_step(a, ph, ph, want_outputs=False)
+            allreduce(reg)
+        outs = [e.disc_step(a, E.D_ADAM, E.D_ADAM) for e, a in zip(ranks, da)]
+        if t == 0:
+            np.testing.assert_allclose(outs[0], ref['disc'][t], rtol=3e-4, atol=3e-5)
+        np.testing.assert_allclose(outs[1], outs[0], rtol=0, atol=0)
+        ga = [E.Engine.gen_args(_t(case.x_unl2[t][r * h:(r + 1) * h])) for r in range(2)]
+        for ph, reg in ((E.G_GEN, E.REGION_BN_STATS), (E.G_FEAT, E.REGION_FM_MOMENTS), (E.G_BWD, E.REGION_BN_BWD), (E.G_TAIL, E.REGION_GRAD_G)):
+            for e, a in zip(ranks, ga):
+                e.gen_step(a, ph, ph, want_outputs=False)
+            allreduce(reg)
+        for e, a in zip(ranks, ga):
+            e.gen_step(a, E.G_ADAM, E.G_ADAM)
+    w0, w1 = ranks[0].get_weights(E.NET_D), ranks[1].get_weights(E.NET_D)
+    for a, b in zip(w0 + ranks[0].get_weights(E.NET_G), w1 + ranks[1].get_weights(E.NET_G)):
+        np.testing.assert_array_equal(a, b)                    # replicas stay bit-identical
+    errs = [update_rel_err(w, wr, wi) for w, wr, wi in zip(w0, ref['d'], case.d0)]
+    assert 1e-6 < max(errs) < 0.3, errs                        # bf16-rounded gradients through two Adam updates
+    for e in ranks:
+        e.close()
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_fp8_phase_protocol_equals_whole_steps(exact):
     """fp8 through the data-parallel phase protocol (mr_gan_amd/dist.py, one rank): with synchronised statistics the HOST runs
@@ -907,6 +958,43 @@ def test_pair_with_shared_generator_pass_equals_separate_substeps(dtype):
         for a, b in zip(res[0][0], other[0]):
             np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(np.asarray(res[0][1]), np.asarray(other[1]))
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_phase_graphs_equal_eager_phases(exact):
+    """MRGAN_FLAG_GRAPH on a data-parallel handle: every phase range of the protocol (mr_gan_amd/dist.py) is captured once and
+    replayed.  Same kernels, same arguments: the weights after several pairs are bit-identical to the eagerly launched phases,
+    with and without the pair hint."""
+    from mr_gan_amd import MRGAN, engine as E
+    from mr_gan_amd.dist import DataParallel, EngineBackend, dp_flags
+    rs = np.random.RandomState(3)
+    B, D, n = 64, 40, 256
+    X = rs.randn(n, D).astype(np.float32)
+    xl = rs.randn(2 * B, D).astype(np.float32)
+    yl = rs.randint(0, 6, size=2 * B).astype(np.int32)
+    res = []
+    for graph in (False, True):
+        m = MRGAN(D, batch_size=B, dtype='bfloat16', seed=77, use_graph=False, flags=dp_flags(exact, graph=graph))
+        dp = DataParallel(EngineBackend(m.engine), exact=exact)
+        with m._on_stream():
+            xu, xlab = m._dev(X), m._dev(xl)
+            idx_lab = m._dev(np.arange(n, dtype=np.int32) % (2 * B), torch.int32)
+            labs = m._dev(yl[np.arange(n) % (2 * B)], torch.int32)
+            idx_u1 = m._dev(np.arange(n, dtype=np.int32)[::-1].copy(), torch.int32)
+            idx_u2 = m._dev(np.roll(np.arange(n, dtype=np.int32), 7), torch.int32)
+            dargs = E.Engine.disc_args(xlab, labs, xu, None, idx_lab, idx_u1, stream_mode=1)
+            gargs = E.Engine.gen_args(xu, None, idx_u2, stream_mode=1)
+            for epoch in range(3):                             # the batch counter is rewound: the same graphs serve every epoch
+                m.engine.set_iterations(2 * epoch * (n // B), 0)
+                for _ in range(n // B):
+                    dp.train_pair(dargs, gargs)
+            torch.cuda.synchronize()
+            metrics = m.engine.read_metrics(reset=True)
+        res.append((m.get_weights('discriminator') + m.get_weights('generator'), metrics))
+        m.engine.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(np.asarray(res[0][1]), np.asarray(res[1][1]))
 
 
 def _dp_worker(rank, world, port, exact, q):
