@@ -150,6 +150,7 @@ __device__ __forceinline__ void chain_head(const ChainArgs& a, char* lds, Stream
     __bf16* w6t = (__bf16*)(lds + a.head_scratch_off);        // [3][KMAX][CH_PW]
     __bf16* dl_rc = w6t + 3 * KMAX * CH_PW;                   // [3][CH_ROWS][KMAX]   dlogits addends, row-major
     __bf16* dl_t = dl_rc + 3 * CH_ROWS * KMAX;                // [3][KMAX][CH_ROWS]   ... class-major
+    float* red = (float*)(dl_t + 3 * KMAX * CH_ROWS);         // [3 + KMAX][CH_ROWS]  per-row loss terms and dlogits (fp32)
     float* lpart = (float*)oimg;                              // [8 waves][CH_ROWS][KMAX]: dead before the dpre image is written
     const int lane = t & 63, lc = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -281,15 +282,12 @@ __device__ __forceinline__ void chain_head(const ChainArgs& a, char* lds, Stream
 #pragma unroll
             for (int c = 0; c < KMAX; ++c) dl_t[(q * KMAX + c) * CH_ROWS + r] = d3[q][c];
         }
-        loss0 = wave_sum(loss0); loss1 = wave_sum(loss1); err = wave_sum(err);
-        float dsum[KMAX];                                     // db6 = column sums of dlogits
+        // the eleven per-row quantities whose sums over the 64 rows leave the block (three loss terms, db6 = column sums of
+        // dlogits): to LDS, row-contiguous; eleven lanes of the last wave add them up behind the barrier (as wave-wide shuffle
+        // reductions -- eleven six-step ds_bpermute chains on this one wave -- they cost ~3 us with the other seven waves waiting)
+        red[0 * CH_ROWS + r] = loss0; red[1 * CH_ROWS + r] = loss1; red[2 * CH_ROWS + r] = err;
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) dsum[c] = wave_sum(dl[c]);
-        if (lane == 0) {
-            *(f32x4*)(h.loss_part + blk * 4) = (f32x4){loss0, loss1, err, 0.f};
-            *(f32x4*)(part_row + h.off_db) = (f32x4){dsum[0], dsum[1], dsum[2], dsum[3]};
-            *(f32x4*)(part_row + h.off_db + 4) = (f32x4){dsum[4], dsum[5], dsum[6], dsum[7]};
-        }
+        for (int c = 0; c < KMAX; ++c) red[(3 + c) * CH_ROWS + r] = dl[c];
     }
     lds_barrier();
 
@@ -355,6 +353,18 @@ __device__ __forceinline__ void chain_head(const ChainArgs& a, char* lds, Stream
         }
         const int j = wave * 32 + lc;                         // registers 0 .. 3 = classes 4 lh .. 4 lh + 3 of feature j
         if (j < h.feat) *(f32x4*)(part_row + (long)j * KMAX + 4 * lh) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    }
+    if (wave == CH_THREADS / 64 - 1 && lane < 3 + KMAX) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < CH_ROWS / 4; ++i) {
+            const f32x4 v = *(const f32x4*)(red + lane * CH_ROWS + 4 * i);
+            s4[i & 3] += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const float tot = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        if (lane < 3) h.loss_part[blk * 4 + lane] = tot;
+        else part_row[h.off_db + lane - 3] = tot;
+        if (lane == 0) h.loss_part[blk * 4 + 3] = 0.f;
     }
     lds_barrier();
     // dL/d(pre5): the next product's A image is complete; its copy for the weight-gradient launch leaves at the end of that
