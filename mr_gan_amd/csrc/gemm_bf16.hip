@@ -612,7 +612,8 @@ __global__ void tr_probe_kernel(unsigned short* out) {
 // epilogue variants compiled for the bf16 path (anything else is a host-side error)
 // tile configs: 0 = 64x128 / 4 waves / 3 stages ; 1 = 128x128 / 4 waves / 2 stages ; 2 = 256x128 / 8 waves / 2 stages ;
 //               3 = 256x256 / 8 waves / 2 stages ; 4 = cfg 0 with pipelined fragments ; 5 = 64x128 / 4 waves / 2 stages
-//               (three blocks per CU).  mrgan_set_tuning(MRGAN_TUNE_KC_CFG) forces one; default picks by grid size.
+//               (three blocks per CU) ; 6 = 128x256 / 8 waves ; 7 = 128x128 / EIGHT waves of 64x32 / 2 stages.
+//               mrgan_set_tuning(MRGAN_TUNE_KC_CFG) forces one; default picks by grid size.
 template <int EPI, int VAR>
 static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
     const int forced = g.e.tune_kc_cfg;
@@ -621,13 +622,16 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         // measured on MI355X (scripts/gemm_bench.py): bigger tiles win once they still give >= ~1.5 blocks per CU
         const int t128 = ceil_div(g.M, 128) * ceil_div(g.N, 128) * g.nbatch;
         const int t256 = ceil_div(g.M, 256) * ceil_div(g.N, 256) * g.nbatch;
-        cfg = t128 >= 384 ? 1 : 0;
+        // 128 x 128 tiles as EIGHT waves of 64 x 32 (cfg 7; two blocks = 16 waves per CU): more waves hide the barrier -> LDS read ->
+        // MFMA chain of the short k-loops better than four waves of 64 x 64 (cfg 1) although they read 1.5 instead of 1.0
+        // fragments per MFMA: D1 forward over 3 segments 22.9 -> 21.3 us, dX through D2 20.3 -> 18.7 us (scripts/gemm_bench.py)
+        cfg = t128 >= 384 ? 7 : 0;
         // long reductions with enough 256x256 tiles to fill the chip (the wide stack of BASELINE configs[4]: K = N = 4096):
         // 128 flop per staged byte instead of 64 -- 1.37 vs 0.95 PFLOP/s measured at 24576 x 4096 x 4096 (scripts/fp8_bench.py)
         if (g.K >= 2048 && t256 >= 256 && (g.N % 256) == 0) cfg = 3;
         // long reductions into a narrow output (D2 forward: K = 1024, N = 512): three 64x128 blocks per CU with a
         // 2-stage ring hide the k-loop latency better than two 128x128 blocks (20.7 vs 21.7 us)
-        if (EPI == EPI_FWD && cfg == 1 && g.K >= 1024 && g.K < 2048 && g.N <= 512) cfg = 5;
+        if (EPI == EPI_FWD && cfg == 7 && g.K >= 1024 && g.K < 2048 && g.N <= 512) cfg = 5;
     }
     if (cfg >= 2 && (g.N % 128) != 0) cfg = 0;
     if (cfg == 6 && (g.N % 256) != 0) cfg = 1;
@@ -635,6 +639,7 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
     constexpr bool H_TILE = EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU;
     if (H_TILE && cfg >= 2) cfg = 1;
     if constexpr (!H_TILE) {
+        if (cfg == 7) return launch_kc<EPI, 128, 128, 2, 4, 2, VAR>(g, s);
         if (cfg == 6 && (g.N % 256) == 0) return launch_kc<EPI, 128, 256, 2, 4, 2, VAR>(g, s);      // 8 waves of 64x64
         if (cfg == 2) return launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
         if (cfg == 3) return (g.N % 256) == 0 ? launch_kc<EPI, 256, 256, 2, 4, 2, VAR>(g, s) : launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
