@@ -169,7 +169,8 @@ enum {
     MRGAN_TUNE_KC_CFG = 1,       /* forward / input-gradient tile: -1 (default) measured table; 0 64x128/3 stages,
                                   * 1 128x128, 2 256x128, 3 256x256, 4 64x128 pipelined fragments, 5 64x128/2 stages  */
     MRGAN_TUNE_KC_PIPE = 2,      /* 1: pipelined-fragment variant for launches with <= 1 tile per CU (default 0)       */
-    MRGAN_TUNE_KS_W8 = 3,        /* 1: 8-wave blocks in the grouped weight-gradient launch (default 0: 4 waves)        */
+    MRGAN_TUNE_KS_W8 = 3,        /* grouped weight-gradient launch: 0 (default) 8 waves, two blocks per CU; 1: 8 waves with a
+                                  * 3-stage ring, one block per CU; 2: 4 waves, two blocks per CU                           */
     MRGAN_TUNE_KS_GROUP = 4,     /* 0: one launch per weight gradient instead of one grouped launch (default 1)        */
     MRGAN_TUNE_PAIR_GEN = 5      /* 0: mrgan_train_pair runs the two generator forwards separately (default 1: as one) */
 };

@@ -1652,7 +1652,7 @@ int mrgan_set_tuning(mrgan_handle* h, int knob, int value) {
         case MRGAN_TUNE_CHAIN: h->use_chain = value != 0 && h->chain_ok; break;
         case MRGAN_TUNE_KC_CFG: h->tune_kc_cfg = value; break;
         case MRGAN_TUNE_KC_PIPE: h->tune_bits = (h->tune_bits & ~TUNE_BIT_KC_PIPE) | (value ? TUNE_BIT_KC_PIPE : 0); break;
-        case MRGAN_TUNE_KS_W8: h->tune_bits = (h->tune_bits & ~TUNE_BIT_KS_W8) | (value ? TUNE_BIT_KS_W8 : 0); break;
+        case MRGAN_TUNE_KS_W8: h->tune_bits = (h->tune_bits & ~(TUNE_BIT_KS_W8 | TUNE_BIT_KS_W4)) | (value == 1 ? TUNE_BIT_KS_W8 : value == 2 ? TUNE_BIT_KS_W4 : 0); break;
         case MRGAN_TUNE_KS_GROUP: h->tune_bits = (h->tune_bits & ~TUNE_BIT_NO_KS_GROUP) | (value ? 0 : TUNE_BIT_NO_KS_GROUP); break;
         case MRGAN_TUNE_PAIR_GEN: h->tune_pair_gen = value ? 1 : 0; break;
         default: return fail(-1, "unknown tuning knob %d", knob);

@@ -420,7 +420,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MR][NR], const GemmArgs& 
 #undef EPI_STAMP
 }
 
-enum { TUNE_BIT_KC_PIPE = 1, TUNE_BIT_KS_W8 = 2, TUNE_BIT_NO_KS_GROUP = 4 };
+enum { TUNE_BIT_KC_PIPE = 1, TUNE_BIT_KS_W8 = 2, TUNE_BIT_NO_KS_GROUP = 4, TUNE_BIT_KS_W4 = 8 };
 // up to KS_GROUP_MAX weight-gradient products launched as one grid (gemm_bf16.hip)
 constexpr int KS_GROUP_MAX = 6;
 // a fold of per-block partial rows that rides along in the grouped launch (the loss head's weight-gradient partials):

@@ -697,14 +697,14 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
         grp.fold.blocks_x = ceil_div(fold->n, 256);
         total += grp.fold.blocks_x * fold->ngroups;
     }
-    // The loop is bound by the LDS: ds_read_b64_tr_b16 moves 512 B per wave-instruction, and 128x128 blocks of 8 waves
-    // (64x32 per wave) need 1.5 of them per MFMA.  Four waves of 64x64 need 1.0, and with a 2-stage ring (64 KiB) two
-    // such blocks share a CU, which keeps 8 waves per CU for latency hiding: grouped D products 63 -> ~45 us.
-    // TUNE_BIT_KS_W8 selects the 8-wave / 3-stage blocks (one per CU) again.
+    // Block shape, by measurement (B = 4096, D = 512, the discriminator's launch): 8 waves of 64x32 with a 2-stage ring, two
+    // blocks = 16 waves per CU: 58.7 us; 4 waves of 64x64, two blocks per CU (round 2's default, 1.0 instead of 1.5 transposing
+    // reads per MFMA): 64.7 us; 8 waves with a 3-stage ring, one block per CU: 89 us.  More resident waves hide the
+    // barrier -> LDS read -> MFMA chain; the LDS read rate is not the limit at two blocks per CU.
+    // MRGAN_TUNE_KS_W8: 0 (default) the first, 1 the third, 2 the second.
     constexpr int STAGE = 2 * 64 * 256;
-    const int w8 = gs[0].e.tune_bits & TUNE_BIT_KS_W8;
-    static DeviceOnce attr8, attr4;
-    if (w8) {
+    static DeviceOnce attr8, attr4, attr16;
+    if (gs[0].e.tune_bits & TUNE_BIT_KS_W8) {
         auto kern = gemm_bf16_ks_group_kernel<3, 2, 4>;
         if (attr8.first()) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE) != hipSuccess) return -2;
@@ -712,7 +712,7 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
         }
         MRGAN_LAUNCH(kern, dim3(total), dim3(512), 3 * STAGE, s, grp);
         if (kname) *kname = "gemm_bf16_ks_group_kernel<3, 2, 4>";
-    } else {
+    } else if (gs[0].e.tune_bits & TUNE_BIT_KS_W4) {
         auto kern = gemm_bf16_ks_group_kernel<2, 2, 2>;
         if (attr4.first()) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) return -2;
@@ -720,6 +720,14 @@ int launch_gemm_bf16_dw_group(const GemmArgs* gs, int n, hipStream_t s, const ch
         }
         MRGAN_LAUNCH(kern, dim3(total), dim3(256), 2 * STAGE, s, grp);
         if (kname) *kname = "gemm_bf16_ks_group_kernel<2, 2, 2>";
+    } else {
+        auto kern = gemm_bf16_ks_group_kernel<2, 2, 4>;
+        if (attr16.first()) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) return -2;
+            attr16.mark();
+        }
+        MRGAN_LAUNCH(kern, dim3(total), dim3(512), 2 * STAGE, s, grp);
+        if (kname) *kname = "gemm_bf16_ks_group_kernel<2, 2, 4>";
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
