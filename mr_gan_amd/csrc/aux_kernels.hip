@@ -51,24 +51,9 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
     const long o = sg.stream ? (long)st.batch * sg.rows : 0;
     T* out = (T*)sg.out;
     const bool noisy = sg.gen || sg.sigma > 0.f;
-    if (noisy) {
-        const uint32_t rowhash = noise_rowhash(noise_key(a.seed, sg.site * 256u + sg.seg, st.iter + sg.iter_off), a.row0 + (uint32_t)(rbase + lc));
-        const i32x4 hfrag = hadamard_frag(lane);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const int c0 = cbase + cb * 32;
-            if (c0 >= sg.cols) break;                              // wave-uniform; columns beyond are never read back
-            const i32x16 nz = noise_block(rowhash, (uint32_t)c0 >> 5, lane, hfrag);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) nlds[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][cb * 32 + lc] = (short)nz[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                           // same wave, in-order LDS: the reads below see the writes
-    }
     const float sigs = (sg.gen ? 1.0f : sg.sigma) * NOISE_SCALE;
     const int cg = (lane & 15) * 8, rl = lane >> 4;                // lane <-> (8 columns, every 4th row)
     const int col = cbase + cg;
-    if (col >= sg.cols_pad) return;
     const bool vec_ok = !sg.gen && (sg.ld & 3) == 0 && ((uintptr_t)sg.src & 15) == 0 && col + 7 < sg.cols;
     // source rows first, then every row's loads in flight together (a dependent index -> row chain per iteration is
     // latency-bound: this kernel is 40 MB of traffic and must not take longer than a GEMM)
@@ -93,6 +78,23 @@ __global__ __launch_bounds__(256) void stage_kernel(const StageArgs a) {
             }
         }
     }
+    // the noise of the wave's 32 x 128 block is generated while the row loads above are in flight (it was generated first in
+    // round 2, with nothing in flight)
+    if (noisy) {
+        const uint32_t rowhash = noise_rowhash(noise_key(a.seed, sg.site * 256u + sg.seg, st.iter + sg.iter_off), a.row0 + (uint32_t)(rbase + lc));
+        const i32x4 hfrag = hadamard_frag(lane);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int c0 = cbase + cb * 32;
+            if (c0 >= sg.cols) break;                              // wave-uniform; columns beyond are never read back
+            const i32x16 nz = noise_block(rowhash, (uint32_t)c0 >> 5, lane, hfrag);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nlds[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][cb * 32 + lc] = (short)nz[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // same wave, in-order LDS: the reads below see the writes
+    }
+    if (col >= sg.cols_pad) return;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int rr = it * 4 + rl, row = rbase + rr;
