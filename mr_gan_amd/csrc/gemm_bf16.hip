@@ -612,7 +612,8 @@ __global__ void tr_probe_kernel(unsigned short* out) {
 // epilogue variants compiled for the bf16 path (anything else is a host-side error)
 // tile configs: 0 = 64x128 / 4 waves / 3 stages ; 1 = 128x128 / 4 waves / 2 stages ; 2 = 256x128 / 8 waves / 2 stages ;
 //               3 = 256x256 / 8 waves / 2 stages ; 4 = cfg 0 with pipelined fragments ; 5 = 64x128 / 4 waves / 2 stages
-//               (three blocks per CU) ; 6 = 128x256 / 8 waves ; 7 = 128x128 / EIGHT waves of 64x32 / 2 stages.
+//               (three blocks per CU) ; 6 = 128x256 / 8 waves ; 7 = 128x128 / EIGHT waves of 64x32 / 2 stages ; 9 = 64x64 / 4 waves /
+//               3 stages.
 //               mrgan_set_tuning(MRGAN_TUNE_KC_CFG) forces one; default picks by grid size.
 template <int EPI, int VAR>
 static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
@@ -632,18 +633,23 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         // long reductions into a narrow output (D2 forward: K = 1024, N = 512): three 64x128 blocks per CU with a
         // 2-stage ring hide the k-loop latency better than two 128x128 blocks (20.7 vs 21.7 us)
         if (EPI == EPI_FWD && cfg == 7 && g.K >= 1024 && g.K < 2048 && g.N <= 512) cfg = 5;
+        // launches with at most one 64x128 tile per CU (the one-segment products of the G sub-step, small batches): 64x64 tiles
+        // put twice as many blocks on the chip -- dX through D1 11.5 -> 9.7 us, d(BatchNorm output) 11.0 -> 8.5, G2 forward of one
+        // segment 8.6 -> 7.4; with two tiles per CU already (two-segment launches) the smaller tile loses (10.5 -> 12.4)
+        if (cfg == 0 && ceil_div(g.M, 64) * ceil_div(g.N, 128) * g.nbatch <= 256) cfg = 9;
     }
-    if (cfg >= 2 && (g.N % 128) != 0) cfg = 0;
+    if (cfg >= 2 && cfg != 9 && (g.N % 128) != 0) cfg = 0;
     if (cfg == 6 && (g.N % 256) != 0) cfg = 1;
     // DX epilogues that may stage a tile of e.h in LDS (softplus derivative, xhat sums) only exist for the small tiles
     constexpr bool H_TILE = EPI == EPI_DX && (VAR & VAR_ACT_MASK) != ACT_RELU;
-    if (H_TILE && cfg >= 2) cfg = 1;
+    if (H_TILE && cfg >= 2 && cfg != 9) cfg = 1;
     if constexpr (!H_TILE) {
         if (cfg == 7) return launch_kc<EPI, 128, 128, 2, 4, 2, VAR>(g, s);
         if (cfg == 6 && (g.N % 256) == 0) return launch_kc<EPI, 128, 256, 2, 4, 2, VAR>(g, s);      // 8 waves of 64x64
         if (cfg == 2) return launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
         if (cfg == 3) return (g.N % 256) == 0 ? launch_kc<EPI, 256, 256, 2, 4, 2, VAR>(g, s) : launch_kc<EPI, 256, 128, 4, 2, 2, VAR>(g, s);
     }
+    if (cfg == 9) return launch_kc<EPI, 64, 64, 2, 2, 3, VAR>(g, s);       // 48 KiB ring: three blocks per CU
     if (cfg == 1) return launch_kc<EPI, 128, 128, 2, 2, 2, VAR>(g, s);
     if (cfg == 5) return launch_kc<EPI, 64, 128, 2, 2, 2, VAR>(g, s);      // 48 KiB ring: three blocks per CU
     // cfg 4 / TUNE_BIT_KC_PIPE (launches with at most one 64x128 tile per CU): pipelined fragments, 4-stage ring.
