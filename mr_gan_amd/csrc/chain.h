@@ -25,6 +25,11 @@ constexpr int CH_BUF0 = 0, CH_BUF0_BYTES = CH_ROWS * CH_KMAX * 2;               
 constexpr int CH_BUF1 = CH_BUF0 + CH_BUF0_BYTES, CH_BUF1_BYTES = CH_ROWS * CH_PW * 2;   // 32 KiB: up to 256 columns
 constexpr int CH_RING = CH_BUF1 + CH_BUF1_BYTES, CH_STAGE_BYTES = CH_PW * 128;     // 32 KiB per stage
 constexpr int CH_LDS_BYTES = CH_RING + 2 * CH_STAGE_BYTES;                         // 160 KiB: the whole CU
+// the same map for blocks of `rows` rows (64, or 32 for launches with few row blocks): image 0 | image 1 | the 2-stage ring
+constexpr int chain_buf0(int rows) { return 0; }
+constexpr int chain_buf1(int rows) { return rows * CH_KMAX * 2; }
+constexpr int chain_ring(int rows) { return rows * (CH_KMAX + CH_PW) * 2; }
+constexpr int chain_lds_bytes(int rows) { return chain_ring(rows) + 2 * CH_STAGE_BYTES; }
 
 enum { CH_OP_GEMM = 0, CH_OP_HEAD = 1 };
 enum { CH_FWD_RELU = 0, CH_DX_RELU = 1 };
@@ -52,6 +57,7 @@ struct ChainArgs {
     int variant;                       // CH_V_*
     int nops; ChainOp op[CH_MAX_OPS];
     int rows, nseg, S;                 // valid rows per segment, segments, segment stride (rows)
+    int block_rows;                    // rows per block: 64, or 32 (CH_V_GFWD / CH_V_GBWD only)
     int a_kind;                        // how the first A image is produced
     const __bf16* a; long a_bs; int lda; int a_cols;      // CH_A_GLOBAL: rows of a[seg][S][lda], a_cols (padded) columns
     // CH_A_FMGRAD: A = relu-mask ? gj : 0 with gj from the feature-matching moments (mr_gan.py:152-154)

@@ -337,7 +337,7 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     // ---- partial sums ----------------------------------------------------------------------------
     h->cs_bn1 = a.take<float>(2 * (size_t)tm * N1p); h->cs_bn2 = a.take<float>(2 * (size_t)tm * N1p);
     for (int l = 0; l < 4; ++l) h->cs_db[l] = a.take<float>(3 * (size_t)tm * h->d[l].Np);
-    h->cs_f = a.take<float>(2 * (size_t)tm * h->Fp);
+    h->cs_f = a.take<float>(2 * (size_t)ceil_div(B, 32) * h->Fp);      // per (segment, row block): 64-row tiles, or the chain's 32-row blocks
     h->cs_db3g = a.take<float>((size_t)tm * h->Dp);
     h->cs_db2g = a.take<float>((size_t)tm * h->g[1].Np);
     h->cs_dbeta = a.take<float>((size_t)tm * N1p); h->cs_dgamma = a.take<float>((size_t)tm * N1p);
@@ -881,8 +881,10 @@ ChainOp chain_dx_op(mrgan_handle* h, int l, int a_off, int o_off, bool bias_sums
     if (bias_sums) { o.cs = h->cs_db[l - 1]; o.ldcs = L.Kp; }
     return o;
 }
+// rows per block of a G sub-step chain launch: 32 when 64-row blocks would leave more than half of the CUs without a block
+int chain_block_rows(const mrgan_handle* h, int nseg) { return nseg * ceil_div(h->B, 64) <= 128 ? 32 : 64; }
 void chain_common(mrgan_handle* h, ChainArgs& c, int nseg) {
-    c.rows = h->B; c.nseg = nseg; c.S = h->S; c.seg0 = 0;
+    c.rows = h->B; c.nseg = nseg; c.S = h->S; c.seg0 = 0; c.block_rows = 64;
     c.seed = h->cfg.seed; c.row0 = (uint32_t)(h->cfg.rank * h->B); c.st = h->state + h->cur;
     c.ablate = h->ablate;
 }
@@ -1087,21 +1089,27 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
             memset(&c, 0, sizeof c);
             chain_common(h, c, 2);
             c.variant = CH_V_GFWD;
+            c.block_rows = chain_block_rows(h, 2);
+            const int b0 = chain_buf0(c.block_rows), b1 = chain_buf1(c.block_rows);
             c.a_kind = CH_A_GLOBAL; c.a = (const __bf16*)h->xin[2]; c.a_bs = (long)h->S * h->d[2].Kp; c.lda = h->d[2].Kp; c.a_cols = h->d[2].Kp;
-            c.op[0] = chain_fwd_op(h, 2, CH_BUF0, CH_BUF1, false);
-            c.op[1] = chain_fwd_op(h, 3, CH_BUF1, CH_BUF0, false);
-            c.op[2] = chain_fwd_op(h, 4, CH_BUF0, CH_BUF1, true);       // + the feature-matching column sums
+            c.op[0] = chain_fwd_op(h, 2, b0, b1, false);
+            c.op[1] = chain_fwd_op(h, 3, b1, b0, false);
+            c.op[2] = chain_fwd_op(h, 4, b0, b1, true);       // + the feature-matching column sums (one partial row per row block)
             c.nops = 3;
             CHK(run_chain(h, c, chain_flops(h, c, false), s));
         }
         if (h->sync_stats) {
-            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f, h->cs_f + (size_t)tm * h->Fp, tm, h->Fp, h->Fp, h->r_fm, s));
+            const int np = h->use_chain ? ceil_div(B, chain_block_rows(h, 2)) : tm;
+            PROF("colsum_finalize_kernel", launch_colsum_finalize(h->cs_f, h->cs_f + (size_t)np * h->Fp, np, h->Fp, h->Fp, h->r_fm, s));
         }
     } else if (phase == MRGAN_G_BWD) {
         FmArgs f;
         memset(&f, 0, sizeof f);
         if (h->sync_stats) { f.cs = h->r_fm; f.npart_fake = 1; f.npart_real = 1; }
-        else { f.cs = h->cs_f; f.npart_fake = tm; f.npart_real = tm; }
+        else {          // per-row-block partial sums as the producer left them: 64-row tiles, or the chain launch's row blocks
+            const int np = h->use_chain ? ceil_div(B, chain_block_rows(h, 2)) : tm;
+            f.cs = h->cs_f; f.npart_fake = np; f.npart_real = np;
+        }
         f.ldcs = h->Fp; f.count = h->stat_count; f.grad_scale = h->fm_scale; f.feat = h->Fp; f.feat_valid = h->F;
         f.mask = h->mask[4]; f.ldm = h->ldm[4]; f.dpre = h->dpre[4]; f.ldd = h->Fp; f.rows = B;
         f.loss_out = h->step_out + 3; f.accum = h->accum + 3;
@@ -1113,10 +1121,12 @@ int gen_phase(mrgan_handle* h, const mrgan_gen_args* a, int phase, hipStream_t s
             memset(&c, 0, sizeof c);
             chain_common(h, c, 1);
             c.variant = CH_V_GBWD;
+            c.block_rows = chain_block_rows(h, 1);
+            const int b0 = chain_buf0(c.block_rows), b1 = chain_buf1(c.block_rows);
             c.a_kind = CH_A_FMGRAD; c.fm = f; c.fm_feat = (const __bf16*)h->feat; c.fm_ldf = h->Fp;
-            c.op[0] = chain_dx_op(h, 4, CH_BUF0, CH_BUF1, false);
-            c.op[1] = chain_dx_op(h, 3, CH_BUF1, CH_BUF0, false);
-            c.op[2] = chain_dx_op(h, 2, CH_BUF0, CH_BUF1, false);
+            c.op[0] = chain_dx_op(h, 4, b0, b1, false);
+            c.op[1] = chain_dx_op(h, 3, b1, b0, false);
+            c.op[2] = chain_dx_op(h, 2, b0, b1, false);
             c.nops = 3;
             CHK(run_chain(h, c, chain_flops(h, c, false), s));
         } else {

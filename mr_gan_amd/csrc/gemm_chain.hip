@@ -22,8 +22,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 // byte offset of element (row, col) inside an activation image
+template <int ROWS = CH_ROWS>
 __device__ __forceinline__ int act_off(int row, int col) {
-    return (col >> 6) * (CH_ROWS * 128) + kc_off(row, (col & 63) >> 3) + (col & 7) * 2;
+    return (col >> 6) * (ROWS * 128) + kc_off(row, (col & 63) >> 3) + (col & 7) * 2;
 }
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
@@ -74,12 +75,13 @@ __device__ __forceinline__ void issue_btile(const BTile& b, int pass, int kt, ch
 }
 
 // copy a [64 rows][256 columns] bf16 LDS image (columns col0 .. of the global tensor) out with 16-byte stores
+template <int ROWS = CH_ROWS>
 __device__ __forceinline__ void copy_out(const char* img, __bf16* out, int ldo, int col0, int ncols, int rows_valid, int t) {
 #pragma unroll
-    for (int u = 0; u < CH_ROWS * CH_PW / 8 / CH_THREADS; ++u) {
+    for (int u = 0; u < ROWS * CH_PW / 8 / CH_THREADS; ++u) {
         const int q = t + CH_THREADS * u, r = q >> 5, cch = q & 31;
         if (r < rows_valid && col0 + cch * 8 < ncols)
-            *(u32x4*)(out + (long)r * ldo + col0 + cch * 8) = *(const u32x4*)(img + (cch >> 3) * (CH_ROWS * 128) + kc_off(r, cch & 7));
+            *(u32x4*)(out + (long)r * ldo + col0 + cch * 8) = *(const u32x4*)(img + (cch >> 3) * (ROWS * 128) + kc_off(r, cch & 7));
     }
 }
 
@@ -93,8 +95,9 @@ struct Stream {
     // first tile), and the following wait comes a whole epilogue later.  The image is read-only until the product after next.
     const char* cp_img; __bf16* cp_out; int cp_ldo, cp_col0, cp_ncols;
 };
+template <int ROWS = CH_ROWS>
 __device__ __forceinline__ void flush_copy(Stream& sm, int rows_valid, int t) {
-    if (sm.cp_img) copy_out(sm.cp_img, sm.cp_out, sm.cp_ldo, sm.cp_col0, sm.cp_ncols, rows_valid, t);
+    if (sm.cp_img) copy_out<ROWS>(sm.cp_img, sm.cp_out, sm.cp_ldo, sm.cp_col0, sm.cp_ncols, rows_valid, t);
     sm.cp_img = nullptr;
 }
 
@@ -376,13 +379,24 @@ __device__ __forceinline__ void chain_head(const ChainArgs& a, char* lds, Stream
 // ------------------------------------------------------------------------------------------------------------------
 // feature-matching gradient as the first A image (mr_gan.py:152-154): dL/d(pre5) = relu-mask ? 2/(J B) (m_gen - m_real) : 0
 // ------------------------------------------------------------------------------------------------------------------
+template <int ROWS>
 __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int a_off, int rb, int row_blk, int rows_valid, int t
 #ifdef MRGAN_STAMPS
                                              , unsigned long long (&st_acc)[8], unsigned long long& st_prev
 #endif
 ) {
     const FmArgs& f = a.fm;
-    float* gj = (float*)(lds + CH_RING + CH_STAGE_BYTES);     // the second ring stage is idle until the first k-tile step
+    // the stored features of this block's rows (their sign is relu'(pre5), used at the end): requested first, so that their round
+    // trip runs beside the fold of the partial sums instead of behind it
+    constexpr int NCH = ROWS * CH_PW / 8 / CH_THREADS;
+    bf16x8 fv[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        const int q = t + CH_THREADS * u, r = q >> 5, c0 = (q & 31) * 8;
+        const bool ok = r < rows_valid && c0 < f.feat;
+        fv[u] = *(const bf16x8*)(a.fm_feat + (long)(row_blk + (ok ? r : 0)) * a.fm_ldf + (ok ? c0 : 0));
+    }
+    float* gj = (float*)(lds + chain_ring(ROWS) + CH_STAGE_BYTES);     // the second ring stage is idle until the first k-tile step
     float* scr = gj + CH_PW;                                  // [8][256]
     const float* cs_real = f.cs + (long)f.npart_fake * f.ldcs;
     // fold the per-row-block partial sums: thread <-> (4 columns, every 8th partial row), all loads of a thread in flight
@@ -437,14 +451,6 @@ __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int 
     // generated rows (f > 0 <=> pre5 > 0; bf16 keeps every positive value positive): one unconditional 16-byte load per chunk
     // from a clamped row, all four in flight together.  (Decoding the lane-native mask words here instead costs 8 scattered
     // loads per chunk: ~18 k cycles per block, measured.)
-    constexpr int NCH = CH_ROWS * CH_PW / 8 / CH_THREADS;
-    bf16x8 fv[NCH];
-#pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-        const int q = t + CH_THREADS * u, r = q >> 5, c0 = (q & 31) * 8;
-        const bool ok = r < rows_valid && c0 < f.feat;
-        fv[u] = *(const bf16x8*)(a.fm_feat + (long)(row_blk + (ok ? r : 0)) * a.fm_ldf + (ok ? c0 : 0));
-    }
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
         const int q = t + CH_THREADS * u, r = q >> 5, cch = q & 31, c0 = cch * 8;
@@ -452,7 +458,7 @@ __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int 
         bf16x8 v;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (__bf16)((ok && (float)fv[u][i] > 0.f) ? gj[c0 + i] : 0.f);
-        *(bf16x8*)(img + (cch >> 3) * (CH_ROWS * 128) + kc_off(r, cch & 7)) = v;
+        *(bf16x8*)(img + (cch >> 3) * (ROWS * 128) + kc_off(r, cch & 7)) = v;
     }
     __syncthreads();
     CH_STAMP(6);
@@ -461,10 +467,10 @@ __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int 
 
 // one dense product of the chain on the block's rows.  MODE is compile-time; `bias` (forward) and `mw` (the relu-mask words
 // of the output tile: read by dX, returned by forward) live in registers, loaded or produced before this call.
-template <int MODE>
+template <int MODE, int MI>
 __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op, const __bf16* nextW, const int nextK, const int nextN,
                                            char* lds, Stream& sm, const float bias,
-                                           uint32_t (&mw)[2][2], const int seg, const int nrb, const int rb, const int row_blk,
+                                           uint32_t (&mw)[2][MI], const int seg, const int nrb, const int rb, const int row_blk,
                                            const int rows_valid, const uint32_t iter, const i32x4 hfrag, const int t
 #ifdef MRGAN_STAMPS
                                            , unsigned long long (&st_acc)[8], unsigned long long& st_prev
@@ -473,14 +479,17 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
     const int lane = t & 63, lc = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr bool fwd = MODE == CH_FWD_RELU;
+    constexpr int ROWS = 32 * MI;
     const int K = op.K, N = op.N, a_off = op.a_off, o_off = op.o_off;
     const int npass = (N + CH_PW - 1) / CH_PW, nk = K / 64;
     const bool noisy = fwd && op.sigma > 0.f;
-    uint32_t rowhash[2] = {0u, 0u};
+    uint32_t rowhash[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) rowhash[mi] = 0u;
     if (noisy) {
         const uint32_t nkey = noise_key(a.seed, op.site * 256u + (uint32_t)(a.seg0 + seg), iter);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) rowhash[mi] = noise_rowhash(nkey, a.row0 + (uint32_t)(row_blk + mi * 32 + lc));
+        for (int mi = 0; mi < MI; ++mi) rowhash[mi] = noise_rowhash(nkey, a.row0 + (uint32_t)(row_blk + mi * 32 + lc));
     }
     uint16_t* mask = op.mask ? op.mask + (long)seg * op.mask_bs : nullptr;
     BTile bt;
@@ -490,9 +499,9 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
         if (pass >= npass) break;
         const int col = pass * CH_PW + wave * 32 + lc;
         const bool colin = col < N, colvalid = col < op.n_valid;
-        f32x16 acc[2];
+        f32x16 acc[MI];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
         CH_STAMP(1);               // pass setup
@@ -506,37 +515,36 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
             if (!(a.ablate & CH_ABL_STREAM)) wait_vm(0);          // this wave's pieces of tile gtile have landed (anything older: long done)
             CH_STAMP(3);                                   // wait for the weight tile
             if (!(a.ablate & CH_ABL_STREAM)) {
-                char* stage = lds + CH_RING + ((sm.gtile + 1) & 1) * CH_STAGE_BYTES;
+                char* stage = lds + chain_ring(ROWS) + ((sm.gtile + 1) & 1) * CH_STAGE_BYTES;
                 if (kt + 1 < nk) issue_btile(bt, pass, kt + 1, stage, wave);
                 else if (pass + 1 < npass) issue_btile(bt, pass + 1, 0, stage, wave);
                 else if (nextW) { BTile nb; btile_setup(nb, nextW, nextK, nextN, wave, lane); issue_btile(nb, 0, 0, stage, wave); }
             }
-            const char* As = lds + a_off + kt * (CH_ROWS * 128);
-            const char* Bs = lds + CH_RING + (sm.gtile & 1) * CH_STAGE_BYTES;
+            const char* As = lds + a_off + kt * (ROWS * 128);
+            const char* Bs = lds + chain_ring(ROWS) + (sm.gtile & 1) * CH_STAGE_BYTES;
             ++sm.gtile;
             // fragments of two k-steps per batch: their LDS latency is paid once per batch (the other wave of the SIMD
             // covers the rest); a deeper batch costs registers the epilogue needs
             if (a.ablate & CH_ABL_MFMA) continue;
 #pragma unroll
             for (int kg = 0; kg < 4; kg += 2) {
-                bf16x8 fa[2][2], fb[2];
+                bf16x8 fa[2][MI], fb[2];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    fa[ks][0] = *(const bf16x8*)(As + kc_off(lc, (kg + ks) * 2 + lh));
-                    fa[ks][1] = *(const bf16x8*)(As + kc_off(32 + lc, (kg + ks) * 2 + lh));
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) fa[ks][mi] = *(const bf16x8*)(As + kc_off(mi * 32 + lc, (kg + ks) * 2 + lh));
                     fb[ks] = *(const bf16x8*)(Bs + kc_off(wave * 32 + lc, (kg + ks) * 2 + lh));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0], fb[ks], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][1], fb[ks], acc[1], 0, 0, 0);
-                }
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi], fb[ks], acc[mi], 0, 0, 0);
             }
             CH_STAMP(5);                                   // tile issue + fragment reads + MFMAs
         }
 
-        if (!(a.ablate & CH_ABL_COPY)) flush_copy(sm, rows_valid, t);      // the previous pass's image -> HBM (see Stream)
+        if (!(a.ablate & CH_ABL_COPY)) flush_copy<ROWS>(sm, rows_valid, t);      // the previous pass's image -> HBM (see Stream)
         // every pass of a product assembles its 256 columns in the SAME image: a second pass may only overwrite them when every
         // wave has copied the first pass's out (the only such product, dX through D3, ends the chain)
         if (pass > 0) lds_barrier();
@@ -548,7 +556,7 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
         int obase[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            obase[i] = (cip >> 6) * (CH_ROWS * 128) + lh * 512 + (((((cip & 63) >> 3) ^ (lh << 1)) ^ ((i & 1) | ((i >> 1) << 2))) << 4) + (cip & 7) * 2;
+            obase[i] = (cip >> 6) * (ROWS * 128) + lh * 512 + (((((cip & 63) >> 3) ^ (lh << 1)) ^ ((i & 1) | ((i >> 1) << 2))) << 4) + (cip & 7) * 2;
         const float sig = (noisy && colvalid) ? op.sigma * NOISE_SCALE : 0.f;
         float s1 = 0.f;
         auto ostore = [&](int mi, int r, float o) {
@@ -562,7 +570,7 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
         } else if constexpr (fwd) {
             const float bv = colvalid ? bias : 0.f;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
                 i32x16 nzs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 if (noisy) nzs = noise_block(rowhash[mi], (uint32_t)col >> 5, lane, hfrag);
                 uint32_t mbits = 0u;
@@ -584,7 +592,7 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
             }
         } else {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     // rows >= rows_valid and padding columns arrive as exact zeros (zero A rows / zero weights).
@@ -597,10 +605,10 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
             }
         }
         if (op.cs) {
-            if (fwd && rows_valid < CH_ROWS) {                 // ragged block: the column sum again, without the padding rows
+            if (fwd && rows_valid < ROWS) {                 // ragged block: the column sum again, without the padding rows
                 s1 = 0.f;
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s1 += (mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < rows_valid) ? acc[mi][r] : 0.f;
             }
@@ -618,13 +626,14 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
 }
 
 // relu-mask words of a dX product's output tile, from HBM (written by an earlier launch)
-__device__ __forceinline__ void load_mask_words(const ChainArgs& a, const ChainOp& op, uint32_t (&mw)[2][2], int seg, int row_blk, int wave, int lc, int lh) {
+template <int MI>
+__device__ __forceinline__ void load_mask_words(const ChainArgs& a, const ChainOp& op, uint32_t (&mw)[2][MI], int seg, int row_blk, int wave, int lc, int lh) {
     const uint16_t* mask = op.mask + (long)seg * op.mask_bs;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int col = pass * CH_PW + wave * 32 + lc;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             // branch-free (see chain_fmgrad): clamped address, result zeroed when out of range
             const bool ok = col < op.N && row_blk + mi * 32 < a.rows;
             const uint32_t w = mask[((long)((ok ? row_blk + mi * 32 : 0) >> 5) * op.ldm + (ok ? col : 0)) * 2 + lh];
@@ -643,14 +652,17 @@ __device__ __forceinline__ void load_mask_words(const ChainArgs& a, const ChainO
 // unrolled at compile time: epilogue inputs are loaded once at the top (before the weight stream loads the memory
 // pipeline), relu masks of products whose forward ran in this launch never leave registers, and no per-op descriptor
 // reload sits between two products.
-template <int VARIANT>
+// MI: 32-row groups per block (2: 64 rows, the D sub-step's launch; 1: 32 rows, for launches that would leave most CUs idle)
+template <int VARIANT, int MI>
 __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
+    constexpr int ROWS = 32 * MI;
+    static_assert(VARIANT != CH_V_DTAIL || MI == 2, "the loss head works on 64-row blocks");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63, lc = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int nrb = (a.rows + CH_ROWS - 1) / CH_ROWS;
+    const int nrb = (a.rows + ROWS - 1) / ROWS;
     const int seg = blockIdx.x / nrb, rb = blockIdx.x - seg * nrb;
-    const int row_blk = rb * CH_ROWS, rows_valid = min(CH_ROWS, a.rows - row_blk);
+    const int row_blk = rb * ROWS, rows_valid = min(ROWS, a.rows - row_blk);
 
 #ifdef MRGAN_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
@@ -662,18 +674,22 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     // ---- epilogue inputs of every product: biases (forward) and the relu masks that come from HBM ----
     const int col0 = wave * 32 + lc;
     float bias[3] = {0.f, 0.f, 0.f};
-    uint32_t mwA[2][2] = {{0u, 0u}, {0u, 0u}}, mwB[2][2] = {{0u, 0u}, {0u, 0u}}, mwC[2][2] = {{0u, 0u}, {0u, 0u}};
+    uint32_t mwA[2][MI], mwB[2][MI], mwC[2][MI];
+#pragma unroll
+    for (int p_ = 0; p_ < 2; ++p_)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { mwA[p_][mi] = 0u; mwB[p_][mi] = 0u; mwC[p_][mi] = 0u; }
     if constexpr (VARIANT != CH_V_GBWD) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) { const float bv = a.op[i].bias[min(col0, a.op[i].n_valid - 1)]; bias[i] = col0 < a.op[i].n_valid ? bv : 0.f; }
     }
-    if constexpr (VARIANT == CH_V_DTAIL) load_mask_words(a, a.op[6], mwC, seg, row_blk, wave, lc, lh);      // dX through D3 needs D2's mask
+    if constexpr (VARIANT == CH_V_DTAIL) load_mask_words<MI>(a, a.op[6], mwC, seg, row_blk, wave, lc, lh);      // dX through D3 needs D2's mask
     HeadInputs hin;
     if constexpr (VARIANT == CH_V_DTAIL) head_prefetch(a, hin, seg, row_blk, rows_valid, t);
     if constexpr (VARIANT == CH_V_GBWD) {
-        load_mask_words(a, a.op[0], mwA, seg, row_blk, wave, lc, lh);
-        load_mask_words(a, a.op[1], mwB, seg, row_blk, wave, lc, lh);
-        load_mask_words(a, a.op[2], mwC, seg, row_blk, wave, lc, lh);
+        load_mask_words<MI>(a, a.op[0], mwA, seg, row_blk, wave, lc, lh);
+        load_mask_words<MI>(a, a.op[1], mwB, seg, row_blk, wave, lc, lh);
+        load_mask_words<MI>(a, a.op[2], mwC, seg, row_blk, wave, lc, lh);
     }
 
     // ---- first A image ----
@@ -682,23 +698,24 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
         const __bf16* src = a.a + (long)seg * a.a_bs;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)((long)a.rows * a.lda * 2), 0x00020000);
         const int lrow = lane >> 3, lp = lane & 7, nkt = a.a_cols / 64;
-        // 8 pieces of [8 rows][128 B] per k-tile, spread over the waves: rows >= a.rows arrive as zeros
-        for (int pce = wave; pce < nkt * 8; pce += CH_THREADS / 64) {
-            const int kt = pce >> 3, R = (pce & 7) * 8 + lrow;
+        // ROWS / 8 pieces of [8 rows][128 B] per k-tile, spread over the waves: rows >= a.rows arrive as zeros
+        constexpr int PPT = ROWS / 8;
+        for (int pce = wave; pce < nkt * PPT; pce += CH_THREADS / 64) {
+            const int kt = pce / PPT, pr = pce - kt * PPT, R = pr * 8 + lrow;
             const int voff = (int)(((long)(row_blk + R) * a.lda + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
-            glds16(rsA, lds + a0_off + kt * (CH_ROWS * 128) + (pce & 7) * 1024, voff, kt * 128);
+            glds16(rsA, lds + a0_off + kt * (ROWS * 128) + pr * 1024, voff, kt * 128);
         }
     }
     // ---- the weight-tile stream (per wave: its own 32 columns of every tile) ----
     Stream sm;
     sm.gtile = 0; sm.cp_img = nullptr;
-    { BTile b0; btile_setup(b0, a.op[0].W, a.op[0].K, a.op[0].N, wave, lane); issue_btile(b0, 0, 0, lds + CH_RING, wave); }
+    { BTile b0; btile_setup(b0, a.op[0].W, a.op[0].K, a.op[0].N, wave, lane); issue_btile(b0, 0, 0, lds + chain_ring(ROWS), wave); }
     if constexpr (VARIANT != CH_V_GBWD) {
         wait_vm(4);                // this wave's pieces of the A image have landed (the 4 weight-tile pieces are younger) ...
         __builtin_amdgcn_s_barrier();      // ... everyone's: the k-loops below run without workgroup barriers
         asm volatile("" ::: "memory");
     } else {
-        chain_fmgrad(a, lds, a0_off, rb, row_blk, rows_valid, t CH_ST_ARGS);      // (ends with a workgroup barrier)
+        chain_fmgrad<ROWS>(a, lds, a0_off, rb, row_blk, rows_valid, t CH_ST_ARGS);      // (ends with a workgroup barrier)
         sm.cp_img = lds + a0_off; sm.cp_out = (__bf16*)a.fm.dpre + (long)row_blk * a.fm.ldd;
         sm.cp_ldo = a.fm.ldd; sm.cp_col0 = 0; sm.cp_ncols = a.fm.feat;
     }
@@ -713,23 +730,23 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     // NEXT: index of the product that follows (-1: none) -- its first weight tile is issued during this product's last k-tile
 #define CH_GEMM(MODE, I, NEXT, BIAS, MW) do { const ChainOp op_ = a.op[opq(I)];                                                          \
         const int nx_ = opq(NEXT < 0 ? 0 : NEXT);                                                                                      \
-        chain_gemm<MODE>(a, op_, NEXT < 0 ? nullptr : a.op[nx_].W, a.op[nx_].K, a.op[nx_].N, lds, sm, BIAS, MW, seg, nrb, rb, row_blk,  \
+        chain_gemm<MODE, MI>(a, op_, NEXT < 0 ? nullptr : a.op[nx_].W, a.op[nx_].K, a.op[nx_].N, lds, sm, BIAS, MW, seg, nrb, rb, row_blk,  \
                          rows_valid, iter, hfrag, t CH_ST_ARGS); } while (0)
     if constexpr (VARIANT == CH_V_DTAIL) {
         // D3 D4 D5 forward: the masks of D3 / D4 stay in registers for the way back
-        uint32_t mw4[2][2];
+        uint32_t mw4[2][MI];
         CH_GEMM(CH_FWD_RELU, 0, 1, bias[0], mwB);
         CH_GEMM(CH_FWD_RELU, 1, 2, bias[1], mwA);
         CH_GEMM(CH_FWD_RELU, 2, 4, bias[2], mw4);
         CH_STAMP(1);               // (the feature image is complete: chain_gemm ended with the image barrier; the weight tile in
                                    //  flight lands in the ring, which the head does not touch)
-        if (!(a.ablate & CH_ABL_HEAD)) chain_head(a, lds, sm, hin, mw4, seg, rb, nrb, row_blk, rows_valid, t);
+        if constexpr (MI == 2) { if (!(a.ablate & CH_ABL_HEAD)) chain_head(a, lds, sm, hin, mw4, seg, rb, nrb, row_blk, rows_valid, t); }
         CH_STAMP(2);               // loss head
         CH_GEMM(CH_DX_RELU, 4, 5, 0.f, mwA);       // dX through D5 * relu'(D4)
         CH_GEMM(CH_DX_RELU, 5, 6, 0.f, mwB);       // dX through D4 * relu'(D3)
         CH_GEMM(CH_DX_RELU, 6, -1, 0.f, mwC);       // dX through D3 * relu'(D2)
     } else if constexpr (VARIANT == CH_V_GFWD) {
-        uint32_t mwx[2][2];
+        uint32_t mwx[2][MI];
         CH_GEMM(CH_FWD_RELU, 0, 1, bias[0], mwx);
         CH_GEMM(CH_FWD_RELU, 1, 2, bias[1], mwx);
         CH_GEMM(CH_FWD_RELU, 2, -1, bias[2], mwx);
@@ -739,7 +756,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
         CH_GEMM(CH_DX_RELU, 2, -1, 0.f, mwC);
     }
 #undef CH_GEMM
-    if (!(a.ablate & CH_ABL_COPY)) flush_copy(sm, rows_valid, t);      // the last image
+    if (!(a.ablate & CH_ABL_COPY)) flush_copy<ROWS>(sm, rows_valid, t);      // the last image
 #ifdef MRGAN_STAMPS
     if (a.stamps && t == 0)
         for (int i = 0; i < 8; ++i) a.stamps[(long)blockIdx.x * 8 + i] = st_acc[i];
@@ -749,9 +766,11 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
 }  // namespace
 
 int chain_init_attributes() {
-    hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_DTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GFWD>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GBWD>, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_DTAIL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(64));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GFWD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(64));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GBWD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(64));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GFWD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(32));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GBWD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(32));
     return e == hipSuccess ? 0 : -2;
 }
 
@@ -762,6 +781,7 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
                                             {CH_OP_GEMM, CH_OP_GEMM, CH_OP_GEMM, -1, -1, -1, -1, -1}};
     static const int nops[3] = {7, 3, 3};
     if (a.variant < 0 || a.variant > 2 || a.nops != nops[a.variant]) return -3;
+    if (a.block_rows != 64 && !(a.block_rows == 32 && a.variant != CH_V_DTAIL)) return -3;
     for (int i = 0; i < a.nops; ++i) {
         const ChainOp& op = a.op[i];
         if (op.kind != want[a.variant][i]) return -3;
@@ -775,11 +795,14 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
         if ((long)op.N * op.K * 2 >= (1L << 31)) return -3;
     }
     if (a.variant != CH_V_GBWD && ((a.a_cols % 64) || a.a_cols > CH_KMAX || a.a_cols != a.op[0].K || (long)a.rows * a.lda * 2 >= (1L << 31))) return -3;
-    const int nrb = (a.rows + CH_ROWS - 1) / CH_ROWS;
+    const int nrb = (a.rows + a.block_rows - 1) / a.block_rows;
     const dim3 grid(nrb * a.nseg), block(CH_THREADS);
-    if (a.variant == CH_V_DTAIL) MRGAN_LAUNCH(chain_kernel<CH_V_DTAIL>, grid, block, CH_LDS_BYTES, s, a);
-    else if (a.variant == CH_V_GFWD) MRGAN_LAUNCH(chain_kernel<CH_V_GFWD>, grid, block, CH_LDS_BYTES, s, a);
-    else MRGAN_LAUNCH(chain_kernel<CH_V_GBWD>, grid, block, CH_LDS_BYTES, s, a);
+    const int lds = chain_lds_bytes(a.block_rows);
+    if (a.variant == CH_V_DTAIL) MRGAN_LAUNCH((chain_kernel<CH_V_DTAIL, 2>), grid, block, lds, s, a);
+    else if (a.variant == CH_V_GFWD && a.block_rows == 64) MRGAN_LAUNCH((chain_kernel<CH_V_GFWD, 2>), grid, block, lds, s, a);
+    else if (a.variant == CH_V_GFWD) MRGAN_LAUNCH((chain_kernel<CH_V_GFWD, 1>), grid, block, lds, s, a);
+    else if (a.block_rows == 64) MRGAN_LAUNCH((chain_kernel<CH_V_GBWD, 2>), grid, block, lds, s, a);
+    else MRGAN_LAUNCH((chain_kernel<CH_V_GBWD, 1>), grid, block, lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

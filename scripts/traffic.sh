@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 10 --warmup 2 --profile-steps 2 --no-cpu-baseline --no-graph > gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python3 bench.py --steps 10 --warmup 2 --profile-steps 2 --no-cpu-baseline --no-graph --min-seconds 0 > gpurun_out/pmc_$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, json
