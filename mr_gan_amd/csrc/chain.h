@@ -29,7 +29,8 @@ constexpr int CH_LDS_BYTES = CH_RING + 2 * CH_STAGE_BYTES;                      
 constexpr int chain_buf0(int rows) { return 0; }
 constexpr int chain_buf1(int rows) { return rows * CH_KMAX * 2; }
 constexpr int chain_ring(int rows) { return rows * (CH_KMAX + CH_PW) * 2; }
-constexpr int chain_lds_bytes(int rows) { return chain_ring(rows) + 2 * CH_STAGE_BYTES; }
+constexpr int chain_stages(int rows) { return rows <= 32 ? 3 : 2; }      // ring depth: what fits beside the images in 160 KiB
+constexpr int chain_lds_bytes(int rows) { return chain_ring(rows) + chain_stages(rows) * CH_STAGE_BYTES; }
 
 enum { CH_OP_GEMM = 0, CH_OP_HEAD = 1 };
 enum { CH_FWD_RELU = 0, CH_DX_RELU = 1 };

@@ -882,7 +882,11 @@ ChainOp chain_dx_op(mrgan_handle* h, int l, int a_off, int o_off, bool bias_sums
     return o;
 }
 // rows per block of a G sub-step chain launch: 32 when 64-row blocks would leave more than half of the CUs without a block
-int chain_block_rows(const mrgan_handle* h, int nseg) { return nseg * ceil_div(h->B, 64) <= 128 ? 32 : 64; }
+// (the 3-stage weight ring of the 32-row blocks keeps two k-tiles in flight: every reduction of the chain must have two)
+int chain_block_rows(const mrgan_handle* h, int nseg) {
+    const int kmin = std::min(std::min(h->d[2].Kp, h->d[2].Np), std::min(h->d[3].Np, h->d[4].Np));
+    return (nseg * ceil_div(h->B, 64) <= 128 && kmin >= 128) ? 32 : 64;
+}
 void chain_common(mrgan_handle* h, ChainArgs& c, int nseg) {
     c.rows = h->B; c.nseg = nseg; c.S = h->S; c.seg0 = 0; c.block_rows = 64;
     c.seed = h->cfg.seed; c.row0 = (uint32_t)(h->cfg.rank * h->B); c.st = h->state + h->cur;

@@ -41,7 +41,8 @@ __device__ __forceinline__ void wait_vm(int n) {
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     }
 }
 
@@ -87,7 +88,8 @@ __device__ __forceinline__ void copy_out(const char* img, __bf16* out, int ldo, 
 
 // Shared state of the weight-tile stream of one block (all wave-uniform)
 struct Stream {
-    int gtile;                 // tiles consumed so far: tile g lives in ring stage g & 1
+    int gtile;                 // tiles consumed so far: tile g lives in ring stage g % (number of stages)
+    int inflight;              // tiles issued and not yet consumed (tile gtile is the oldest)
     // The copy of a finished output image to HBM is DEFERRED to the end of the next pass's k-loop.  Stores count in vmcnt in issue
     // order with the weight-tile DMAs: issued right behind the image barrier (round 2) they sat in front of the next tile's
     // DMA, and the wait for that tile -- one k-tile of MFMAs later -- also waited for the stores' acknowledgement (~1 us per
@@ -396,7 +398,7 @@ __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int 
         const bool ok = r < rows_valid && c0 < f.feat;
         fv[u] = *(const bf16x8*)(a.fm_feat + (long)(row_blk + (ok ? r : 0)) * a.fm_ldf + (ok ? c0 : 0));
     }
-    float* gj = (float*)(lds + chain_ring(ROWS) + CH_STAGE_BYTES);     // the second ring stage is idle until the first k-tile step
+    float* gj = (float*)(lds + chain_ring(ROWS) + (chain_stages(ROWS) - 1) * CH_STAGE_BYTES);     // the last ring stage is idle until the first k-tile step
     float* scr = gj + CH_PW;                                  // [8][256]
     const float* cs_real = f.cs + (long)f.npart_fake * f.ldcs;
     // fold the per-row-block partial sums: thread <-> (4 columns, every 8th partial row), all loads of a thread in flight
@@ -479,7 +481,7 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
     const int lane = t & 63, lc = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr bool fwd = MODE == CH_FWD_RELU;
-    constexpr int ROWS = 32 * MI;
+    constexpr int ROWS = 32 * MI, NS = chain_stages(ROWS), AHEAD = NS - 1;
     const int K = op.K, N = op.N, a_off = op.a_off, o_off = op.o_off;
     const int npass = (N + CH_PW - 1) / CH_PW, nk = K / 64;
     const bool noisy = fwd && op.sigma > 0.f;
@@ -512,16 +514,27 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
             // already consumed.  The A image is read-only for the whole product (completed behind the barrier that ended the
             // previous product / the prologue).  The waves of a block drift apart inside a product -- one wave's MFMAs beside
             // another's epilogue -- and meet again at the image barrier that ends the pass.
-            if (!(a.ablate & CH_ABL_STREAM)) wait_vm(0);          // this wave's pieces of tile gtile have landed (anything older: long done)
+            // AHEAD tiles of the flat sequence are in flight while tile gtile is consumed (one with the 2-stage ring of the 64-row
+            // blocks; two with the 3-stage ring that fits beside 32-row images: at one tile the wait below was the L2 round trip of
+            // every tile).  vmcnt counts in issue order: all but the youngest 4 (AHEAD - 1) operations done = tile gtile has landed
+            // (stores issued since then only make the wait stricter).
+            // (sm.inflight tiles are issued and not yet consumed, tile gtile the oldest of them: at the tail of the last product no
+            //  younger tile exists and the wait must cover everything)
+            if (!(a.ablate & CH_ABL_STREAM)) {
+                if constexpr (AHEAD == 1) wait_vm(0);
+                else wait_vm(4 * (sm.inflight - 1));
+            }
+            if constexpr (AHEAD > 1) --sm.inflight;
             CH_STAMP(3);                                   // wait for the weight tile
             if (!(a.ablate & CH_ABL_STREAM)) {
-                char* stage = lds + chain_ring(ROWS) + ((sm.gtile + 1) & 1) * CH_STAGE_BYTES;
-                if (kt + 1 < nk) issue_btile(bt, pass, kt + 1, stage, wave);
-                else if (pass + 1 < npass) issue_btile(bt, pass + 1, 0, stage, wave);
-                else if (nextW) { BTile nb; btile_setup(nb, nextW, nextK, nextN, wave, lane); issue_btile(nb, 0, 0, stage, wave); }
+                char* stage = lds + chain_ring(ROWS) + ((sm.gtile + AHEAD) % NS) * CH_STAGE_BYTES;
+                const int kk = kt + AHEAD;                 // (every product of a chain has at least AHEAD k-tiles: launch_chain)
+                if (kk < nk) { issue_btile(bt, pass, kk, stage, wave); if constexpr (AHEAD > 1) ++sm.inflight; }
+                else if (pass + 1 < npass) { issue_btile(bt, pass + 1, kk - nk, stage, wave); if constexpr (AHEAD > 1) ++sm.inflight; }
+                else if (nextW) { BTile nb; btile_setup(nb, nextW, nextK, nextN, wave, lane); issue_btile(nb, 0, kk - nk, stage, wave); if constexpr (AHEAD > 1) ++sm.inflight; }
             }
             const char* As = lds + a_off + kt * (ROWS * 128);
-            const char* Bs = lds + chain_ring(ROWS) + (sm.gtile & 1) * CH_STAGE_BYTES;
+            const char* Bs = lds + chain_ring(ROWS) + (sm.gtile % NS) * CH_STAGE_BYTES;
             ++sm.gtile;
             // fragments of two k-steps per batch: their LDS latency is paid once per batch (the other wave of the SIMD
             // covers the rest); a deeper batch costs registers the epilogue needs
@@ -708,10 +721,16 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     }
     // ---- the weight-tile stream (per wave: its own 32 columns of every tile) ----
     Stream sm;
-    sm.gtile = 0; sm.cp_img = nullptr;
-    { BTile b0; btile_setup(b0, a.op[0].W, a.op[0].K, a.op[0].N, wave, lane); issue_btile(b0, 0, 0, lds + chain_ring(ROWS), wave); }
+    constexpr int AHEAD = chain_stages(ROWS) - 1;
+    sm.gtile = 0; sm.cp_img = nullptr; sm.inflight = AHEAD;
+    {
+        BTile b0;
+        btile_setup(b0, a.op[0].W, a.op[0].K, a.op[0].N, wave, lane);
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) issue_btile(b0, 0, i, lds + chain_ring(ROWS) + i * CH_STAGE_BYTES, wave);
+    }
     if constexpr (VARIANT != CH_V_GBWD) {
-        wait_vm(4);                // this wave's pieces of the A image have landed (the 4 weight-tile pieces are younger) ...
+        wait_vm(4 * AHEAD);        // this wave's pieces of the A image have landed (the weight-tile pieces are younger) ...
         __builtin_amdgcn_s_barrier();      // ... everyone's: the k-loops below run without workgroup barriers
         asm volatile("" ::: "memory");
     } else {
@@ -788,7 +807,7 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
         if (op.kind != CH_OP_GEMM) continue;
         const bool fwd = a.variant == CH_V_GFWD || (a.variant == CH_V_DTAIL && i < 3);
         if (op.mode != (fwd ? CH_FWD_RELU : CH_DX_RELU)) return -3;
-        if ((op.K % 64) || (op.N % 64) || op.K > CH_KMAX || op.K < 64 || op.N > 2 * CH_PW || !op.W) return -3;
+        if ((op.K % 64) || (op.N % 64) || op.K > CH_KMAX || op.K < 64 * (chain_stages(a.block_rows) - 1) || op.N > 2 * CH_PW || !op.W) return -3;
         if (fwd && op.N > CH_PW) return -3;                    // a forward output is the next product's A image
         if (!fwd && !op.mask) return -3;
         if (fwd && !op.bias) return -3;

@@ -509,6 +509,35 @@ def test_chain_launches_equal_per_layer_launches(D, B):
         assert rel_err(a, b) < 2e-5, ("dG", i, rel_err(a, b))
 
 
+@pytest.mark.parametrize("D,B", [(2432, 1024), (400, 50)])
+def test_substeps_are_bit_reproducible(D, B):
+    """The same D and G sub-step on fresh handles, three times: every gradient and every stored activation identical bit for bit.
+    No atomics and no arrival-order reductions exist on the training path, so any difference is a race --
+    this is the test that caught a too-weak vmcnt wait at the tail of the chain kernel's 3-stage weight ring, which showed up as
+    an intermittent 1e-2 error in one parity case and nowhere else."""
+    from mr_gan_amd import engine as E
+    case = Case(D=D, B=B, steps=1, device_z=True)
+    ref = None
+    for rep in range(3):
+        eng = _engine(D, B, 1, flags=E.FLAG_FLAT_GRADS)
+        _load(eng, case)
+        da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]))
+        eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
+        cur = eng.get_slot(E.NET_D, 2)
+        eng.disc_step(da, E.D_ADAM, E.D_ADAM)
+        ga = E.Engine.gen_args(_t(case.x_unl2[0]))
+        eng.gen_step(ga, E.G_GEN, E.G_TAIL, want_outputs=False)
+        cur += eng.get_slot(E.NET_G, 2)
+        cur += [eng.debug_buffer(0, l, 2).cpu().numpy() for l in range(5)] + [eng.debug_buffer(1, l, 1).cpu().numpy() for l in range(5)]
+        cur.append(eng.debug_buffer(2, 0, 2).cpu().numpy())
+        eng.close()
+        if ref is None:
+            ref = cur
+        else:
+            for i, (a, b) in enumerate(zip(cur, ref)):
+                np.testing.assert_array_equal(a, b, err_msg="tensor %d differs between run %d and run 0" % (i, rep))
+
+
 def test_wide_stack_bf16_matches_bf16_mirror():
     """BASELINE configs[4] geometry at one rank's share: hidden 4096 x 5 (generator 4096 x 2), D = 512, B = 8192 / 8 = 1024.
     The layer widths are literals in the reference (mr_gan.py:111-128); mrgan_config generalises them."""
