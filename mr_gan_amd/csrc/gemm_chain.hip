@@ -398,7 +398,7 @@ __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int 
         const bool ok = r < rows_valid && c0 < f.feat;
         fv[u] = *(const bf16x8*)(a.fm_feat + (long)(row_blk + (ok ? r : 0)) * a.fm_ldf + (ok ? c0 : 0));
     }
-    float* gj = (float*)(lds + chain_ring(ROWS) + (chain_stages(ROWS) - 1) * CH_STAGE_BYTES);     // the last ring stage is idle until the first k-tile step
+    float* gj = (float*)(lds + a.op[0].o_off);               // 9 KiB in the first product's output image: idle until its epilogue (both ring stages are in flight)
     float* scr = gj + CH_PW;                                  // [8][256]
     const float* cs_real = f.cs + (long)f.npart_fake * f.ldcs;
     // fold the per-row-block partial sums: thread <-> (4 columns, every 8th partial row), all loads of a thread in flight
@@ -481,7 +481,7 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
     const int lane = t & 63, lc = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr bool fwd = MODE == CH_FWD_RELU;
-    constexpr int ROWS = 32 * MI, NS = chain_stages(ROWS), AHEAD = NS - 1;
+    constexpr int ROWS = 32 * MI, NS = chain_stages(ROWS);
     const int K = op.K, N = op.N, a_off = op.a_off, o_off = op.o_off;
     const int npass = (N + CH_PW - 1) / CH_PW, nk = K / 64;
     const bool noisy = fwd && op.sigma > 0.f;
@@ -514,45 +514,76 @@ __device__ __forceinline__ void chain_gemm(const ChainArgs& a, const ChainOp& op
             // already consumed.  The A image is read-only for the whole product (completed behind the barrier that ended the
             // previous product / the prologue).  The waves of a block drift apart inside a product -- one wave's MFMAs beside
             // another's epilogue -- and meet again at the image barrier that ends the pass.
-            // AHEAD tiles of the flat sequence are in flight while tile gtile is consumed (one with the 2-stage ring of the 64-row
-            // blocks; two with the 3-stage ring that fits beside 32-row images: at one tile the wait below was the L2 round trip of
-            // every tile).  vmcnt counts in issue order: all but the youngest 4 (AHEAD - 1) operations done = tile gtile has landed
-            // (stores issued since then only make the wait stricter).
+            // Two tiles of the flat sequence are in flight while tile gtile is consumed (at one tile the wait below was the L2 round
+            // trip of every tile).  With the 3-stage ring (32-row blocks) tile gtile + 2 is issued before the reads of tile gtile;
+            // with the 2-stage ring (64-row blocks: the images leave 64 KiB) it goes into tile gtile's OWN stage as soon as this wave
+            // has the tile's four B fragments in registers.  vmcnt counts in issue order: all but the youngest 4 operations done =
+            // tile gtile has landed (stores issued since then only make the wait stricter).
             // (sm.inflight tiles are issued and not yet consumed, tile gtile the oldest of them: at the tail of the last product no
             //  younger tile exists and the wait must cover everything)
             if (!(a.ablate & CH_ABL_STREAM)) {
-                if constexpr (AHEAD == 1) wait_vm(0);
-                else wait_vm(4 * (sm.inflight - 1));
+                if (sm.inflight > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if constexpr (AHEAD > 1) --sm.inflight;
+            --sm.inflight;
             CH_STAMP(3);                                   // wait for the weight tile
-            if (!(a.ablate & CH_ABL_STREAM)) {
-                char* stage = lds + chain_ring(ROWS) + ((sm.gtile + AHEAD) % NS) * CH_STAGE_BYTES;
-                const int kk = kt + AHEAD;                 // (every product of a chain has at least AHEAD k-tiles: launch_chain)
-                if (kk < nk) { issue_btile(bt, pass, kk, stage, wave); if constexpr (AHEAD > 1) ++sm.inflight; }
-                else if (pass + 1 < npass) { issue_btile(bt, pass + 1, kk - nk, stage, wave); if constexpr (AHEAD > 1) ++sm.inflight; }
-                else if (nextW) { BTile nb; btile_setup(nb, nextW, nextK, nextN, wave, lane); issue_btile(nb, 0, kk - nk, stage, wave); if constexpr (AHEAD > 1) ++sm.inflight; }
-            }
+            auto issue_ahead = [&](char* stage) {
+                const int kk = kt + 2;                     // (every product of a chain has at least 2 k-tiles: launch_chain)
+                if (kk < nk) { issue_btile(bt, pass, kk, stage, wave); ++sm.inflight; }
+                else if (pass + 1 < npass) { issue_btile(bt, pass + 1, kk - nk, stage, wave); ++sm.inflight; }
+                else if (nextW) { BTile nb; btile_setup(nb, nextW, nextK, nextN, wave, lane); issue_btile(nb, 0, kk - nk, stage, wave); ++sm.inflight; }
+            };
             const char* As = lds + a_off + kt * (ROWS * 128);
-            const char* Bs = lds + chain_ring(ROWS) + (sm.gtile % NS) * CH_STAGE_BYTES;
+            char* Bs = lds + chain_ring(ROWS) + (sm.gtile % NS) * CH_STAGE_BYTES;
+            if constexpr (NS == 3) { if (!(a.ablate & CH_ABL_STREAM)) issue_ahead(lds + chain_ring(ROWS) + ((sm.gtile + 2) % NS) * CH_STAGE_BYTES); }
             ++sm.gtile;
+            if (a.ablate & CH_ABL_MFMA) { if constexpr (NS == 2) { if (!(a.ablate & CH_ABL_STREAM)) issue_ahead(Bs); } continue; }
             // fragments of two k-steps per batch: their LDS latency is paid once per batch (the other wave of the SIMD
             // covers the rest); a deeper batch costs registers the epilogue needs
-            if (a.ablate & CH_ABL_MFMA) continue;
+            if constexpr (NS == 3) {
 #pragma unroll
-            for (int kg = 0; kg < 4; kg += 2) {
-                bf16x8 fa[2][MI], fb[2];
+                for (int kg = 0; kg < 4; kg += 2) {
+                    bf16x8 fa[2][MI], fb[2];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) fa[ks][mi] = *(const bf16x8*)(As + kc_off(mi * 32 + lc, (kg + ks) * 2 + lh));
-                    fb[ks] = *(const bf16x8*)(Bs + kc_off(wave * 32 + lc, (kg + ks) * 2 + lh));
+                        for (int mi = 0; mi < MI; ++mi) fa[ks][mi] = *(const bf16x8*)(As + kc_off(mi * 32 + lc, (kg + ks) * 2 + lh));
+                        fb[ks] = *(const bf16x8*)(Bs + kc_off(wave * 32 + lc, (kg + ks) * 2 + lh));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi], fb[ks], acc[mi], 0, 0, 0);
+                }
+            } else {
+                // (named registers, not an array: hipcc puts an array it indexes in a loop into scratch memory)
+                const bf16x8 fb0 = *(const bf16x8*)(Bs + kc_off(wave * 32 + lc, 0 + lh)), fb1 = *(const bf16x8*)(Bs + kc_off(wave * 32 + lc, 2 + lh));
+                const bf16x8 fb2 = *(const bf16x8*)(Bs + kc_off(wave * 32 + lc, 4 + lh)), fb3 = *(const bf16x8*)(Bs + kc_off(wave * 32 + lc, 6 + lh));
+                bf16x8 fa0[MI], fa1[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    fa0[mi] = *(const bf16x8*)(As + kc_off(mi * 32 + lc, 0 + lh));
+                    fa1[mi] = *(const bf16x8*)(As + kc_off(mi * 32 + lc, 2 + lh));
+                }
+                // the stage may be refilled once its fragments are in registers (the LDS-DMA write must not overtake the reads)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!(a.ablate & CH_ABL_STREAM)) issue_ahead(Bs);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[mi], fb0, acc[mi], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[mi], fb1, acc[mi], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    fa0[mi] = *(const bf16x8*)(As + kc_off(mi * 32 + lc, 4 + lh));
+                    fa1[mi] = *(const bf16x8*)(As + kc_off(mi * 32 + lc, 6 + lh));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[mi], fb2, acc[mi], 0, 0, 0);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi], fb[ks], acc[mi], 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[mi], fb3, acc[mi], 0, 0, 0);
             }
             CH_STAMP(5);                                   // tile issue + fragment reads + MFMAs
         }
@@ -721,7 +752,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     }
     // ---- the weight-tile stream (per wave: its own 32 columns of every tile) ----
     Stream sm;
-    constexpr int AHEAD = chain_stages(ROWS) - 1;
+    constexpr int AHEAD = 2;       // tiles in flight (see chain_gemm)
     sm.gtile = 0; sm.cp_img = nullptr; sm.inflight = AHEAD;
     {
         BTile b0;
@@ -807,7 +838,7 @@ int launch_chain(const ChainArgs& a, hipStream_t s) {
         if (op.kind != CH_OP_GEMM) continue;
         const bool fwd = a.variant == CH_V_GFWD || (a.variant == CH_V_DTAIL && i < 3);
         if (op.mode != (fwd ? CH_FWD_RELU : CH_DX_RELU)) return -3;
-        if ((op.K % 64) || (op.N % 64) || op.K > CH_KMAX || op.K < 64 * (chain_stages(a.block_rows) - 1) || op.N > 2 * CH_PW || !op.W) return -3;
+        if ((op.K % 64) || (op.N % 64) || op.K > CH_KMAX || op.K < 128 || op.N > 2 * CH_PW || !op.W) return -3;
         if (fwd && op.N > CH_PW) return -3;                    // a forward output is the next product's A image
         if (!fwd && !op.mask) return -3;
         if (fwd && !op.bias) return -3;
