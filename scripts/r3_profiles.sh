@@ -18,4 +18,6 @@ python bench.py --batch 50 --rows 6000 --d 1200 --steps 200 --no-cpu-baseline > 
 for shape in "--d 3632 --batch 512" "--d 2432 --batch 1024" "--d 800 --batch 1024" "--d 400 --batch 1024"; do
   python bench.py $shape --rows 65536 --steps 100 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['roofline'].pop('families',None); print(json.dumps(d))" >> gpurun_out/r3prof/bench_other_shapes.jsonl
 done
+python bench.py --hidden 4096 --batch 8192 --dtype fp8 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r3prof/bench_wide_fp8.json 2>/dev/null
+python bench.py --hidden 4096 --batch 8192 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r3prof/bench_wide_bf16.json 2>/dev/null
 tail -3 gpurun_out/r3prof/mfma_util.txt; tail -4 gpurun_out/r3prof/traffic.log
