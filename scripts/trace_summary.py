@@ -20,6 +20,9 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     per_step = sum(v) / 1e3 / steps
     if per_step < 0.3:
         continue
+    if len(v) < steps:       # not a kernel of the step (the profiled pass's delay kernel, fills and copies of the set-up)
+        print('%-36s %6d %4s %3s %4s %4s %6s %6d %8.1f %9s' % (k[0] or '(not part of a step)', k[1], k[2], k[3], k[4], k[5], k[6], len(v), sum(v) / len(v) / 1e3, 'setup'))
+        continue
     tot += per_step
     print('%-36s %6d %4s %3s %4s %4s %6s %6d %8.1f %9.1f' % (k[0], k[1], k[2], k[3], k[4], k[5], k[6], len(v), sum(v) / len(v) / 1e3, per_step))
 print('total kernel time per step: %.1f us' % tot)
