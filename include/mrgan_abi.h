@@ -172,7 +172,9 @@ enum {
     MRGAN_TUNE_KS_W8 = 3,        /* grouped weight-gradient launch: 0 (default) 8 waves, two blocks per CU; 1: 8 waves with a
                                   * 3-stage ring, one block per CU; 2: 4 waves, two blocks per CU                           */
     MRGAN_TUNE_KS_GROUP = 4,     /* 0: one launch per weight gradient instead of one grouped launch (default 1)        */
-    MRGAN_TUNE_PAIR_GEN = 5      /* 0: mrgan_train_pair runs the two generator forwards separately (default 1: as one) */
+    MRGAN_TUNE_PAIR_GEN = 5,     /* 0: mrgan_train_pair runs the two generator forwards separately (default 1: as one) */
+    MRGAN_TUNE_HEAD_MFMA = 6     /* feature layers wider than 256 columns (bf16 / fp8): 1 (default) the loss head of the D
+                                  * sub-step runs on the matrix cores over 64-row blocks; 0: the scalar head kernel       */
 };
 int mrgan_set_tuning(mrgan_handle* h, int knob, int value);
 

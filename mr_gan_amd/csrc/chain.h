@@ -75,6 +75,18 @@ struct ChainArgs {
 };
 
 int launch_chain(const ChainArgs& a, hipStream_t s);
+
+// Stand-alone loss head on the matrix cores for feature layers the chain cannot hold (wider than 256 columns; BASELINE
+// configs[4]: 4096): the three products of chain_head over 64-row blocks, the feature dimension walked in 256-column chunks.
+// feat % 256 == 0; bf16 features; segment kinds LAB / UNL / FAKE (training); mask = the feature layer's lane-native relu mask.
+struct HeadWideArgs {
+    HeadArgs h;
+    const uint16_t* mask; long mask_bs; int ldm;
+    __bf16* w6c; __bf16* w6r;          // scratch: the bf16 addends of W6, class-major [3][KMAX][feat] and row-major [3][feat][KMAX]
+};
+constexpr int HEAD_WIDE_ROWS = CH_ROWS;
+int launch_w6_split(const HeadWideArgs& a, hipStream_t s);       // first: the addends of the current W6
+int launch_head_wide(const HeadWideArgs& a, hipStream_t s);
 int chain_init_attributes();
 
 }  // namespace mrgan

@@ -135,6 +135,7 @@ struct mrgan_handle {
     Fp8Slot* slots; float* slot_targets; float* accum_save;
     float* fm_scratch; unsigned int* fm_count;       // feature-matching loss partials of a wide feature layer (aux_kernels.hip)
     bool chain_ok, use_chain;            // the 256-wide tail of the discriminator runs as row-block chain launches (gemm_chain.hip)
+    bool head_wide_ok, head_wide; __bf16 *w6c, *w6r;   // feature layers wider than the chain holds: the stand-alone MFMA loss head (chain.h: HeadWideArgs)
     int tune_kc_cfg, tune_bits, tune_pair_gen;      // mrgan_set_tuning
     int ablate;                                      // mrgan_debug_ablate (timing experiments)
     AdamTile *tiles_g_dev, *tiles_d_dev; int ntiles_g, ntiles_d;
@@ -346,6 +347,11 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     // the tail D3..D5 + head as chain launches: bf16, A image <= 512 columns, outputs <= 256 columns
     h->chain_ok = h->bf16 && !h->fp8 && h->d[2].Kp <= CH_KMAX && h->d[2].Np <= CH_PW && h->d[3].Np <= CH_PW && h->d[4].Np <= CH_PW;
     h->use_chain = h->chain_ok;
+    // bf16 / fp8 engines whose feature layer is wider than the chain's 256 columns (the wide stack) run the loss head of the D
+    // sub-step on the matrix cores too (64-row blocks, as the chain's)
+    h->head_wide_ok = h->head_wide = h->bf16 && h->Fp > CH_PW && (h->Fp % CH_PW) == 0;
+    h->w6c = h->w6r = nullptr;
+    if (h->head_wide) { h->w6c = a.take<__bf16>((size_t)3 * KMAX * h->Fp); h->w6r = a.take<__bf16>((size_t)3 * KMAX * h->Fp); }
     h->nblk_head = 3 * ceil_div(B, HEAD_ROWS);                            // capacity; the chain path fills 3 * ceil(B / 64) of them
     h->head_stride = (int)round_up(h->Fp * KMAX + KMAX + h->Fp, 64);      // dW6 | db6 | bias grad of the feature layer
     h->head_groups = std::min(8, 3 * ceil_div(B, CH_ROWS));
@@ -772,7 +778,7 @@ int fp8_disc_fwd(mrgan_handle* h, int nb, bool want_t, bool fm_sums, int x0_slot
     return 0;
 }
 // per-block partial rows the loss head wrote in this sub-step
-int head_blocks(const mrgan_handle* h) { return 3 * ceil_div(h->B, h->use_chain ? CH_ROWS : HEAD_ROWS); }
+int head_blocks(const mrgan_handle* h) { return 3 * ceil_div(h->B, (h->use_chain || h->head_wide) ? CH_ROWS : HEAD_ROWS); }
 
 int run_adam(mrgan_handle* h, int net, int mode, bool with_metrics, hipStream_t s, int advance_batch = 0) {
     AdamArgs a;
@@ -1031,6 +1037,13 @@ int disc_phase(mrgan_handle* h, const mrgan_disc_args* a, int phase, hipStream_t
             c.op[6] = chain_dx_op(h, 2, CH_BUF0, CH_BUF1, true);
             c.nops = 7;
             CHK(run_chain(h, c, chain_flops(h, c, true), s));
+        } else if (h->head_wide) {
+            HeadWideArgs hw;
+            memset(&hw, 0, sizeof hw);
+            hw.h = hd; hw.mask = h->mask[4]; hw.mask_bs = (long)(h->S / 32) * h->ldm[4] * 2; hw.ldm = h->ldm[4];
+            hw.w6c = h->w6c; hw.w6r = h->w6r;
+            PROF("w6_split_kernel", launch_w6_split(hw, s));
+            PROF("head_wide_kernel", launch_head_wide(hw, s));
         } else {
             PROF("head_kernel", launch_head(h->bf16, hd, s));
         }
@@ -1211,10 +1224,10 @@ int sup_step(mrgan_handle* h, const mrgan_sup_args* a, hipStream_t s) {
     const FoldJob fold = {h->head_part, h->head_red, (long)h->head_stride, ceil_div(B, HEAD_ROWS), h->head_stride, h->head_groups, 0};
     CHK(dense_dw_all(h, jobs, 5, B, 1, s, &fold));
     // (the bias / loss partial rows of the two other segments of the GAN step keep the zeros of mrgan_create)
-    const bool chain = h->use_chain;
-    h->use_chain = false;                                   // head_blocks(): the per-layer head wrote 32-row blocks
+    const bool chain = h->use_chain, wide = h->head_wide;
+    h->use_chain = h->head_wide = false;                    // head_blocks(): the per-layer head wrote 32-row blocks
     const int r = run_adam(h, MRGAN_NET_D, ADAM_FUSED, true, s, a->stream_mode ? 1 : 0);
-    h->use_chain = chain;
+    h->use_chain = chain; h->head_wide = wide;
     CHK(r);
     h->cur ^= 1;
     return 0;
@@ -1669,6 +1682,7 @@ int mrgan_set_tuning(mrgan_handle* h, int knob, int value) {
         case MRGAN_TUNE_KS_W8: h->tune_bits = (h->tune_bits & ~(TUNE_BIT_KS_W8 | TUNE_BIT_KS_W4)) | (value == 1 ? TUNE_BIT_KS_W8 : value == 2 ? TUNE_BIT_KS_W4 : 0); break;
         case MRGAN_TUNE_KS_GROUP: h->tune_bits = (h->tune_bits & ~TUNE_BIT_NO_KS_GROUP) | (value ? 0 : TUNE_BIT_NO_KS_GROUP); break;
         case MRGAN_TUNE_PAIR_GEN: h->tune_pair_gen = value ? 1 : 0; break;
+        case MRGAN_TUNE_HEAD_MFMA: h->head_wide = value != 0 && h->head_wide_ok; break;
         default: return fail(-1, "unknown tuning knob %d", knob);
     }
     return 0;

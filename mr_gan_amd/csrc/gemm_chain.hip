@@ -813,7 +813,389 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Stand-alone loss head for wide feature layers (chain.h: HeadWideArgs).  The same three MFMA products as chain_head, with the
+// feature dimension walked in chunks of 256 columns: the block's 64 rows x 256 features arrive by LDS-DMA into one of two
+// images (the next chunk is in flight while the current one is consumed), wave w owns features [32 w, 32 w + 32) of a chunk.
+//   pass 1 (chunks ascending): logits partial products, accumulated over ALL chunks in the wave's registers
+//   row phase (wave 0): losses, error, dlogits as bf16 addends
+//   pass 2 (chunks descending: the last chunk is still resident): dL/d(pre5) of the chunk -> output images -> HBM, dW6^T
+// W6 enters as bf16 addends prepared once per launch by w6_split_kernel (class-major for the logits' B operand, row-major for
+// dL/d(pre5)'s), so a fragment is one 16-byte load from a 200 KB array that stays in L2.
+// Q8: dL/d(pre5) leaves as the two e5m2 images the fp8 products read (row-major and transposed), packed from the accumulators:
+// a lane's four consecutive rows of one column are one dword of the transposed image, the row-major dword comes from a 4 x 4
+// byte transpose inside the lane quad (gemm.h does the same in the fp8 epilogues); both images are assembled in LDS and leave
+// as 16-byte stores.  Otherwise dL/d(pre5) leaves as bf16 through the chain's image + copy_out.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int HW_FIMG = CH_ROWS * CH_PW * 2;                  // 32 KiB per feature image
+constexpr int HW_TPITCH = CH_ROWS + 16, HW_RPITCH = CH_PW + 16;
+constexpr int HW_X = 2 * HW_FIMG, HW_X_BYTES = 40 * 1024;     // pass 1: logits partials; pass 2: output image(s)
+constexpr int HW_SMALL = HW_X + HW_X_BYTES;
+constexpr int HW_LDS = HW_SMALL + 2 * 3 * CH_ROWS * KMAX * 2 + (3 + KMAX) * CH_ROWS * 4;
+static_assert(CH_PW * HW_TPITCH + CH_ROWS * HW_RPITCH <= HW_X_BYTES && 8 * CH_ROWS * KMAX * 4 <= HW_X_BYTES, "head_wide LDS map");
+
+__global__ __launch_bounds__(256) void w6_split_kernel(const float* w, int ldw, int feat, int feat_valid, int classes, __bf16* w6c, __bf16* w6r) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= feat) return;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        const float v = (j < feat_valid && c < classes) ? w[(long)j * ldw + c] : 0.f;
+        __bf16 p0, p1, p2;
+        split3(v, p0, p1, p2);
+        w6c[(0L * KMAX + c) * feat + j] = p0; w6c[(1L * KMAX + c) * feat + j] = p1; w6c[(2L * KMAX + c) * feat + j] = p2;
+        w6r[(0L * feat + j) * KMAX + c] = p0; w6r[(1L * feat + j) * KMAX + c] = p1; w6r[(2L * feat + j) * KMAX + c] = p2;
+    }
+}
+
+template <bool Q8>
+__global__ __launch_bounds__(CH_THREADS) void head_wide_kernel(const HeadWideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const HeadArgs& h = a.h;
+    char* xreg = lds + HW_X;
+    __bf16* dl_rc = (__bf16*)(lds + HW_SMALL);                // [3][CH_ROWS][KMAX]   dlogits addends, row-major
+    __bf16* dl_t = dl_rc + 3 * CH_ROWS * KMAX;                // [3][KMAX][CH_ROWS]   ... class-major
+    float* red = (float*)(dl_t + 3 * KMAX * CH_ROWS);         // [3 + KMAX][CH_ROWS]
+    const int t = threadIdx.x, lane = t & 63, lc = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int seg = blockIdx.y, rb = blockIdx.x, nrb = gridDim.x, kind = h.seg_kind[seg];
+    const int row_blk = rb * CH_ROWS, rows_valid = min(CH_ROWS, h.rows - row_blk), blk = seg * nrb + rb;
+    const int nch = h.feat / CH_PW;
+    const bf16x8 zero8 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+
+    // ---- feature chunks by LDS-DMA: [4 k-tiles][64 rows][64 k] with the chain's swizzle; rows >= h.rows arrive as zeros ----
+    const __bf16* fseg = (const __bf16*)h.f + (long)seg * h.f_bs;
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void*)fseg, 0, (int)((long)h.rows * h.ldf * 2), 0x00020000);
+    int fvoff[4], fdst[4];
+    {
+        const int lrow = lane >> 3, lp = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pce = wave + 8 * i, kt = pce >> 3, pr = pce & 7, R = pr * 8 + lrow;
+            fvoff[i] = (int)(((long)(row_blk + R) * h.ldf + kt * 64 + ((lp ^ ((R >> 1) & 7)) << 3)) * 2);
+            fdst[i] = kt * (CH_ROWS * 128) + pr * 1024;
+        }
+    }
+    auto issue_chunk = [&](int c) {
+        char* img = lds + (c & 1) * HW_FIMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rsF, img + fdst[i], fvoff[i], c * (CH_PW * 2));
+    };
+    // B fragments of the logits product for chunk c: lane <-> (class lc, features 16 (2 wave + u) + 8 lh .. + 7 of the chunk)
+    auto load_w6c = [&](int c, bf16x8 (&fb)[2][3]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const bf16x8 v = *(const bf16x8*)(a.w6c + ((long)p * KMAX + (lc & (KMAX - 1))) * h.feat + c * CH_PW + 16 * (2 * wave + u) + 8 * lh);
+                fb[u][p] = lc < KMAX ? v : zero8;             // columns 8 .. 31 of the product are padding
+            }
+    };
+
+    // =========================== pass 1: logits ===========================
+    f32x16 lacc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lacc[mi][r] = 0.f;
+    bf16x8 fbn[2][3];
+    issue_chunk(0);
+    load_w6c(0, fbn);
+    for (int c = 0; c < nch; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of chunk c and its W6 fragments
+        __builtin_amdgcn_s_barrier();                         // ... everyone's pieces; everyone is done with chunk c - 1
+        asm volatile("" ::: "memory");
+        bf16x8 fb[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[u][p] = fbn[u][p];
+        if (c + 1 < nch) { issue_chunk(c + 1); load_w6c(c + 1, fbn); }
+        const char* fimg = lds + (c & 1) * HW_FIMG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kg = 2 * wave + u;
+            const char* As = fimg + (kg >> 2) * (CH_ROWS * 128);
+            const int ch = (kg & 3) * 2 + lh;
+            const bf16x8 fa0 = *(const bf16x8*)(As + kc_off(lc, ch)), fa1 = *(const bf16x8*)(As + kc_off(32 + lc, ch));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                lacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb[u][p], lacc[0], 0, 0, 0);
+                lacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb[u][p], lacc[1], 0, 0, 0);
+            }
+        }
+    }
+    float* lpart = (float*)xreg;                              // [8 waves][CH_ROWS][KMAX]
+    if (lc < KMAX) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lpart[(wave * CH_ROWS + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * KMAX + lc] = lacc[mi][r];
+    }
+    lds_barrier();
+    // the chunk before the last one is needed next (pass 2 walks downwards): its image is free now
+    if (nch > 1) issue_chunk(nch - 2);
+
+    // =========================== row phase (wave 0: lane <-> row), as chain_head step 3 ===========================
+    float* part_row = h.part + (long)blk * h.part_stride;
+    if (wave == 0) {
+        const int r = lane;
+        float l[KMAX];
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) l[c] = 0.f;
+#pragma unroll
+        for (int w = 0; w < CH_THREADS / 64; ++w) {
+            const f32x4 p0 = *(const f32x4*)(lpart + (w * CH_ROWS + r) * KMAX), p1 = *(const f32x4*)(lpart + (w * CH_ROWS + r) * KMAX + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { l[c] += p0[c]; l[4 + c] += p1[c]; }
+        }
+        const bool rowvalid = r < rows_valid;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+            if (c < h.classes) { l[c] += h.b[c]; mx = fmaxf(mx, l[c]); }
+        }
+        int am = 0;
+        float se = 0.f, p[KMAX];
+#pragma unroll
+        for (int c = KMAX - 1; c >= 0; --c) {
+            p[c] = (c < h.classes) ? expf(l[c] - mx) : 0.f;
+            se += p[c];
+            if (c < h.classes && l[c] == mx) am = c;          // ties -> first index (theano argmax)
+        }
+        const float lse = mx + logf(se);
+        const float inv_se = 1.0f / se;
+        float loss0 = 0.f, loss1 = 0.f, err = 0.f;
+        float dl[KMAX];
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) dl[c] = 0.f;
+        if (rowvalid) {
+            if (kind == HEAD_LAB) {
+                const long lo = h.labels_stream ? (long)h.st->batch * h.rows : 0;
+                const int y = h.labels[lo + row_blk + r];
+                err = (am != y) ? 1.f : 0.f;
+                float ly = 0.f;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) {
+                    if (c == y) ly = l[c];
+                    dl[c] = (p[c] * inv_se - (c == y ? 1.f : 0.f)) * h.inv_count;
+                }
+                loss0 = lse - ly;
+            } else {
+                const float sg = sigmoid_f(lse), sp = softplus_f(lse);
+                const float k = 0.5f * h.inv_count * h.unl_weight * (kind == HEAD_UNL ? (sg - 1.0f) : sg);
+                loss1 = (kind == HEAD_UNL) ? 0.5f * (sp - lse) : 0.5f * sp;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) dl[c] = k * p[c] * inv_se;
+            }
+            if (h.logits) {
+                float* lp = h.logits + (long)seg * h.logits_bs + (long)(row_blk + r) * KMAX;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) lp[c] = (c < h.classes) ? l[c] : 0.f;
+            }
+        }
+        bf16x8 d3[3];
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+            __bf16 p0, p1, p2;
+            split3(dl[c], p0, p1, p2);
+            d3[0][c] = p0; d3[1][c] = p1; d3[2][c] = p2;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            *(bf16x8*)(dl_rc + (q * CH_ROWS + r) * KMAX) = d3[q];
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) dl_t[(q * KMAX + c) * CH_ROWS + r] = d3[q][c];
+        }
+        red[0 * CH_ROWS + r] = loss0; red[1 * CH_ROWS + r] = loss1; red[2 * CH_ROWS + r] = err;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) red[(3 + c) * CH_ROWS + r] = dl[c];
+    }
+    lds_barrier();
+    if (wave == CH_THREADS / 64 - 1 && lane < 3 + KMAX) {     // the eleven sums over the block's rows that leave it
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < CH_ROWS / 4; ++i) {
+            const f32x4 v = *(const f32x4*)(red + lane * CH_ROWS + 4 * i);
+            s4[i & 3] += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const float tot = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        if (lane < 3) h.loss_part[blk * 4 + lane] = tot;
+        else part_row[h.off_db + lane - 3] = tot;
+        if (lane == 0) h.loss_part[blk * 4 + 3] = 0.f;
+    }
+
+    // =========================== pass 2: dL/d(pre5) and dW6^T, chunk by chunk ===========================
+    // A operands that do not depend on the chunk, in registers for the whole pass
+    bf16x8 da[2][3], dt[4][3];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            da[mi][q] = *(const bf16x8*)(dl_rc + (q * CH_ROWS + mi * 32 + lc) * KMAX);
+            if (lh) da[mi][q] = zero8;                        // k = 8 .. 15: padding
+        }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            dt[ks][q] = *(const bf16x8*)(dl_t + (q * KMAX + (lc & (KMAX - 1))) * CH_ROWS + 16 * ks + 8 * lh);
+            if (lc >= KMAX) dt[ks][q] = zero8;
+        }
+    const uint16_t* mseg = a.mask + (long)seg * a.mask_bs;
+    // per chunk: the W6 rows of this lane's feature as bf16 addends (B operand, k = class) and the relu-mask words of its column
+    auto load_chunk_inputs = [&](int c, bf16x8 (&bw)[3], uint32_t (&mw)[2]) {
+        const int col = c * CH_PW + wave * 32 + lc;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const bf16x8 v = *(const bf16x8*)(a.w6r + ((long)q * h.feat + col) * KMAX);
+            bw[q] = lh ? zero8 : v;                           // lh = 1: k = 8 .. 15, zeros
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const bool ok = row_blk + mi * 32 < h.rows;
+            const uint32_t w = mseg[((long)((ok ? row_blk + mi * 32 : 0) >> 5) * a.ldm + col) * 2 + lh];
+            mw[mi] = ok ? w : 0u;
+        }
+    };
+    const float q8s = Q8 ? h.q8_slot->scale : 1.f;
+    float q8_amax = 0.f;
+    bf16x8 bwn[3];
+    uint32_t mwn[2];
+    load_chunk_inputs(nch - 1, bwn, mwn);
+    for (int c = nch - 1; c >= 0; --c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk c (this wave's pieces), its inputs; the previous copy-out
+        __builtin_amdgcn_s_barrier();                         // ... everyone's: the output region and chunk c + 1's image are free
+        asm volatile("" ::: "memory");
+        bf16x8 bw[3];
+        uint32_t mw[2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bw[q] = bwn[q];
+        mw[0] = mwn[0]; mw[1] = mwn[1];
+        if (c >= 1) load_chunk_inputs(c - 1, bwn, mwn);
+        if (c >= 1 && c != nch - 1) issue_chunk(c - 1);       // (chunk nch - 2 was issued before the row phase)
+        const char* fimg = lds + (c & 1) * HW_FIMG;
+        const int c0 = c * CH_PW, cip = wave * 32 + lc;
+        // ---- dL/d(pre5) = (dlogits W6^T) * relu'(pre5): one 16-deep k-step x 6 addend pairs ----
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+            constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+            for (int i = 5; i >= 0; --i)                      // smallest terms first
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[mi][PA[i]], bw[PB[i]], acc[mi], 0, 0, 0);
+            float s1 = 0.f;
+            if constexpr (Q8) {
+                unsigned char* timg = (unsigned char*)xreg;
+                unsigned char* rimg = timg + CH_PW * HW_TPITCH;
+                const int kq = lane & 3;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float o4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r = 4 * g + j;
+                            const float av = acc[mi][r];
+                            o4[j] = ((mw[mi] >> r) & 1u) ? av : 0.f;              // (a select: see chain_gemm)
+                            s1 += o4[j];
+                            q8_amax = fmaxf(q8_amax, fabsf(o4[j]));
+                        }
+                        const uint32_t w = fp8_pack4<FP8_E5M2>(o4[0], o4[1], o4[2], o4[3], q8s);
+                        const int rl = mi * 32 + 8 * g + 4 * lh;                    // rows rl .. rl + 3 of column cip
+                        *(uint32_t*)(timg + cip * HW_TPITCH + rl) = w;
+                        *(uint32_t*)(rimg + (rl + kq) * HW_RPITCH + (cip - kq)) = quad_byte_transpose(w);
+                    }
+            } else {
+                char* oimg = xreg;
+                int obase[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    obase[i] = (cip >> 6) * (CH_ROWS * 128) + lh * 512 + (((((cip & 63) >> 3) ^ (lh << 1)) ^ ((i & 1) | ((i >> 1) << 2))) << 4) + (cip & 7) * 2;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float av = acc[mi][r];
+                        const float v = ((mw[mi] >> r) & 1u) ? av : 0.f;
+                        s1 += v;
+                        *(__bf16*)(oimg + obase[((r >> 1) & 1) | (((r >> 2) & 1) << 1)] + (mi * 32 + (r & 3) + 8 * (r >> 2)) * 128) = (__bf16)v;
+                    }
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            if (lh == 0) part_row[h.off_dbf + c0 + cip] = s1;                   // bias gradient of the feature layer
+        }
+        // ---- dW6^T [class][feature] = dlogits^T F for this wave's 32 features of the chunk ----
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+            const int f0 = wave * 32 + (g4 & 1) * 16 + 4 * pp;
+#pragma unroll
+            for (int ks = 0; ks < CH_ROWS / 16; ++ks) {
+                const int m0 = ks * 16 + (g4 >> 1) * 8 + q;
+                const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(fimg + act_off(m0, f0)));
+                const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(fimg + act_off(m0 + 4, f0)));
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int p = 2; p >= 0; --p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt[ks][p], fb, acc, 0, 0, 0);
+            }
+            *(f32x4*)(part_row + (long)(c0 + cip) * KMAX + 4 * lh) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+        }
+        lds_barrier();                                        // the output image(s) of the chunk are complete
+        if constexpr (Q8) {
+            const unsigned char* timg = (const unsigned char*)xreg;
+            const unsigned char* rimg = timg + CH_PW * HW_TPITCH;
+            unsigned char* q8t = h.q8t ? h.q8t + (long)seg * h.q8t_bs : nullptr;
+            unsigned char* q8 = h.q8 ? h.q8 + (long)seg * h.q8_bs : nullptr;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qi = t + CH_THREADS * u;
+                // transposed copy: column (row of q8t) x 16 rows; rows >= h.rows of the block are zero bytes (zero dlogits)
+                if (q8t) *(u32x4*)(q8t + (long)(c0 + (qi >> 2)) * h.ldq8t + row_blk + 16 * (qi & 3)) = *(const u32x4*)(timg + (qi >> 2) * HW_TPITCH + 16 * (qi & 3));
+                if (q8 && (qi >> 4) < rows_valid) *(u32x4*)(q8 + (long)(row_blk + (qi >> 4)) * h.ldq8 + c0 + 16 * (qi & 15)) = *(const u32x4*)(rimg + (qi >> 4) * HW_RPITCH + 16 * (qi & 15));
+            }
+        } else {
+            copy_out<CH_ROWS>(xreg, (__bf16*)h.dpre + (long)seg * h.dpre_bs + (long)row_blk * h.ldd, h.ldd, c0, h.feat, rows_valid, t);
+        }
+    }
+    if constexpr (Q8) fp8_amax_commit(h.q8_slot, q8_amax);
+}
+
 }  // namespace
+
+// the bf16 addends of W6 for launch_head_wide (once per D sub-step: W6 changes with every Adam update)
+int launch_w6_split(const HeadWideArgs& a, hipStream_t s) {
+    const HeadArgs& h = a.h;
+    if (!a.w6c || !a.w6r || !h.w) return -3;
+    MRGAN_LAUNCH(w6_split_kernel, dim3((h.feat + 255) / 256), dim3(256), 0, s, h.w, h.ldw, h.feat, h.feat_valid, h.classes, a.w6c, a.w6r);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_head_wide(const HeadWideArgs& a, hipStream_t s) {
+    const HeadArgs& h = a.h;
+    if ((h.feat % CH_PW) != 0 || h.classes > KMAX || !a.mask || !a.w6c || !a.w6r || !h.part || !h.loss_part) return -3;
+    for (int i = 0; i < h.nseg; ++i)
+        if (h.seg_kind[i] != HEAD_LAB && h.seg_kind[i] != HEAD_UNL && h.seg_kind[i] != HEAD_FAKE) return -3;
+    if ((long)h.rows * h.ldf * 2 >= (1L << 31)) return -3;
+    const bool q8 = h.q8_slot != nullptr;
+    if (q8 ? !(h.q8 || h.q8t) : !h.dpre) return -3;
+    static DeviceOnce attr;
+    if (attr.first()) {
+        if (hipFuncSetAttribute((const void*)head_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS) != hipSuccess) return -2;
+        if (hipFuncSetAttribute((const void*)head_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS) != hipSuccess) return -2;
+        attr.mark();
+    }
+    const dim3 grid((h.rows + CH_ROWS - 1) / CH_ROWS, h.nseg), block(CH_THREADS);
+    if (q8) MRGAN_LAUNCH((head_wide_kernel<true>), grid, block, HW_LDS, s, a);
+    else MRGAN_LAUNCH((head_wide_kernel<false>), grid, block, HW_LDS, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int chain_init_attributes() {
     hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_DTAIL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(64));

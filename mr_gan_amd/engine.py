@@ -18,7 +18,7 @@ NET_G, NET_D = 0, 1
 FLAG_SYNC_STATS, FLAG_FLAT_GRADS, FLAG_GRAPH, FLAG_GRAD_BF16 = 1, 2, 4, 8
 D_GEN, D_MAIN, D_ADAM = 0, 1, 2
 G_GEN, G_FEAT, G_BWD, G_TAIL, G_ADAM = 0, 1, 2, 3, 4
-TUNE_CHAIN, TUNE_KC_CFG, TUNE_KC_PIPE, TUNE_KS_W8, TUNE_KS_GROUP, TUNE_PAIR_GEN = range(6)
+TUNE_CHAIN, TUNE_KC_CFG, TUNE_KC_PIPE, TUNE_KS_W8, TUNE_KS_GROUP, TUNE_PAIR_GEN, TUNE_HEAD_MFMA = range(7)
 REGION_BN_STATS, REGION_FM_MOMENTS, REGION_BN_BWD, REGION_GRAD_D, REGION_GRAD_G, REGION_WORKSPACE = range(6)
 REGION_GRAD_D_BF16, REGION_GRAD_G_BF16, REGION_TAIL_D, REGION_TAIL_G = 6, 7, 8, 9
 

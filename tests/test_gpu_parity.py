@@ -509,6 +509,38 @@ def test_chain_launches_equal_per_layer_launches(D, B):
         assert rel_err(a, b) < 2e-5, ("dG", i, rel_err(a, b))
 
 
+@pytest.mark.parametrize("dtype,B", [(1, 200), (2, 256)])
+def test_matrix_core_loss_head_equals_scalar_head(dtype, B):
+    """Feature layers wider than the chain holds (here 512 columns = two chunks; BASELINE configs[4]: 4096) run the loss head of
+    the D sub-step as the stand-alone MFMA kernel over 64-row blocks (gemm_chain.hip: head_wide_kernel; TUNE_HEAD_MFMA = 1, the
+    default) instead of head_kernel's fmaf loops over 32-row blocks.  Same rule as the chain test above: three-addend bf16 splits
+    make every product exact, only the fp32 summation order differs -- losses to 1e-6, the bf16 dL/d(pre5) within one ulp on a few
+    rows (fp8 mode: the e5m2 copies are what leaves the kernel; compared through the weight gradients), D gradients to 5e-4.
+    B = 200: a ragged last row block (8 valid rows); dtype 2: the fp8 engine (e5m2 row-major + transposed copies, amax slot)."""
+    from mr_gan_amd import engine as E
+    D, hid = 96, (256, 256, 256, 512, 512)
+    case = Case(D=D, B=B, steps=1, device_z=True, d_hidden=hid)
+    res = []
+    for mfma in (1, 0):
+        eng = _engine(D, B, dtype, flags=E.FLAG_FLAT_GRADS, d_hidden=hid)
+        eng.set_tuning(E.TUNE_HEAD_MFMA, mfma)
+        _load(eng, case)
+        da = E.Engine.disc_args(_t(case.x_lab[0]), _t(case.labels[0], torch.int32), _t(case.x_unl[0]))
+        eng.disc_step(da, E.D_GEN, E.D_MAIN, want_outputs=False)
+        gd = eng.get_slot(E.NET_D, 2)
+        dpre = eng.debug_buffer(1, 4).cpu().numpy()[:, :B] if dtype == 1 else None
+        out = eng.disc_step(da, E.D_ADAM, E.D_ADAM)
+        res.append((gd, out, dpre))
+        eng.close()
+    (gd1, out1, dp1), (gd0, out0, dp0) = res
+    np.testing.assert_allclose(out1, out0, rtol=1e-6, atol=1e-7)
+    if dtype == 1:
+        d = np.abs(dp1 - dp0)
+        assert d.max() <= 2.0 ** -7 * np.abs(dp0).max() and (d.max(axis=2) > 0).mean() < 0.05, (d.max(), (d.max(axis=2) > 0).mean())
+    for i, (a, b) in enumerate(zip(gd1, gd0)):
+        assert rel_err(a, b) < (5e-4 if dtype == 1 else 5e-3), ("dD", i, rel_err(a, b))
+
+
 @pytest.mark.parametrize("D,B", [(2432, 1024), (400, 50)])
 def test_substeps_are_bit_reproducible(D, B):
     """The same D and G sub-step on fresh handles, three times: every gradient and every stored activation identical bit for bit.
