@@ -401,25 +401,28 @@ __device__ __forceinline__ void chain_fmgrad(const ChainArgs& a, char* lds, int 
     float* gj = (float*)(lds + a.op[0].o_off);               // 9 KiB in the first product's output image: idle until its epilogue (both ring stages are in flight)
     float* scr = gj + CH_PW;                                  // [8][256]
     const float* cs_real = f.cs + (long)f.npart_fake * f.ldcs;
-    // fold the per-row-block partial sums: thread <-> (4 columns, every 8th partial row), all loads of a thread in flight
-    // at once (16-byte loads), then an 8-way combine through LDS
+    // fold the per-row-block partial sums: thread <-> (4 columns, every 8th partial row), 64 partial rows of both streams per
+    // round trip (16 loads of 16 bytes in flight per thread), then an 8-way combine through LDS
     {
         const int cq = (t & 63) * 4, pg = t >> 6;
         f32x4 u = {0.f, 0.f, 0.f, 0.f};
         if (cq < f.feat) {
             // unconditional loads from clamped rows, zero weight beyond the end: a load under a runtime condition makes
-            // hipcc branch around it and wait for each one (16 serialized round trips, ~30 k cycles measured here)
-            f32x4 v[8];
+            // hipcc branch around it and wait for each one (16 serialized round trips, ~30 k cycles measured here); and a
+            // remainder loop `for (p = pg + 64; p < npart; p += 8) u += load` is one round trip per iteration (the 32-row
+            // blocks of the G sub-step leave 128 partial rows per stream: 16 of them, 20 k cycles of a 43 k-cycle launch)
+            const int nmax = max(f.npart_fake, f.npart_real);
+            for (int base = 0; base < nmax; base += 64) {
+                f32x4 vf[8], vr[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *(const f32x4*)(f.cs + (long)min(pg + 8 * i, f.npart_fake - 1) * f.ldcs + cq);
-            for (int p = pg + 64; p < f.npart_fake; p += 8) u += *(const f32x4*)(f.cs + (long)p * f.ldcs + cq);
+                for (int i = 0; i < 8; ++i) vf[i] = *(const f32x4*)(f.cs + (long)min(base + pg + 8 * i, f.npart_fake - 1) * f.ldcs + cq);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) u += v[i] * ((pg + 8 * i < f.npart_fake) ? 1.0f : 0.0f);
+                for (int i = 0; i < 8; ++i) vr[i] = *(const f32x4*)(cs_real + (long)min(base + pg + 8 * i, f.npart_real - 1) * f.ldcs + cq);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *(const f32x4*)(cs_real + (long)min(pg + 8 * i, f.npart_real - 1) * f.ldcs + cq);
-            for (int p = pg + 64; p < f.npart_real; p += 8) u -= *(const f32x4*)(cs_real + (long)p * f.ldcs + cq);
+                for (int i = 0; i < 8; ++i) u += vf[i] * ((base + pg + 8 * i < f.npart_fake) ? 1.0f : 0.0f);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) u -= v[i] * ((pg + 8 * i < f.npart_real) ? 1.0f : 0.0f);
+                for (int i = 0; i < 8; ++i) u -= vr[i] * ((base + pg + 8 * i < f.npart_real) ? 1.0f : 0.0f);
+            }
         }
         *(f32x4*)(scr + pg * 256 + cq) = u;                   // scr: [8][256]
     }
