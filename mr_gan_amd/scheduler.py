@@ -31,9 +31,10 @@ def train_job(job, datasets, device):
     return mr_gan(None, None, trainTestSets=sets, device=device, **kw)
 
 
-def _worker(wid, device, runner, inbox, outbox):
+def _worker(wid, device, runner, inbox, out):
+    """inbox: this worker's job queue; out: the sending end of this worker's OWN result pipe (no queue is shared between
+    workers: terminating one of them can neither corrupt nor lock what the others write to)"""
     datasets = {}
-    local = device
     while True:
         msg = inbox.get()
         if msg is None:
@@ -41,13 +42,13 @@ def _worker(wid, device, runner, inbox, outbox):
         kind = msg[0]
         if kind == 'dataset':
             datasets[msg[1]] = (msg[2], msg[3])
-            outbox.put(('ack', wid, msg[1]))
+            out.send(('ack', msg[1]))
         else:
             _, run_id, idx, job = msg
             try:
-                outbox.put(('done', wid, run_id, idx, runner(job, datasets, local)))
+                out.send(('done', run_id, idx, runner(job, datasets, device)))
             except Exception:                                                    # report, keep serving
-                outbox.put(('fail', wid, run_id, idx, traceback.format_exc()))
+                out.send(('fail', run_id, idx, traceback.format_exc()))
 
 
 class RunScheduler(object):
@@ -55,19 +56,36 @@ class RunScheduler(object):
         if gpus < 1 or jobs_per_gpu < 1:
             raise ValueError("gpus and jobs_per_gpu must be positive")
         self.devices = list(devices) if devices is not None else ['cuda:%d' % g for g in range(gpus) for _ in range(jobs_per_gpu)]
-        ctx = mp.get_context('spawn')                       # never fork a process that may have initialised HIP
-        self._ctx, self._runner, self._datasets = ctx, runner, {}
-        self.outbox = ctx.Queue()
-        self.inboxes, self.procs = [], []
-        for wid, dev in enumerate(self.devices):
-            q = ctx.Queue()
-            q.cancel_join_thread()                          # never block interpreter exit on bytes a dead worker will not read
-            p = ctx.Process(target=_worker, args=(wid, dev, runner, q, self.outbox), daemon=True)
-            p.start()
-            self.inboxes.append(q)
-            self.procs.append(p)
+        self._ctx = mp.get_context('spawn')                 # never fork a process that may have initialised HIP
+        self._runner, self._datasets = runner, {}
+        n = len(self.devices)
+        self.inboxes, self.procs, self.results = [None] * n, [None] * n, [None] * n
+        for wid in range(n):
+            self._spawn(wid)
         self._nkeys = 0
+        self._run_id = 0
         self.assignments = []                               # (job index, worker id) of the last run()
+
+    def _spawn(self, wid):
+        q = self._ctx.Queue()
+        q.cancel_join_thread()                              # never block interpreter exit on bytes a dead worker will not read
+        recv, send = self._ctx.Pipe(duplex=False)
+        p = self._ctx.Process(target=_worker, args=(wid, self.devices[wid], self._runner, q, send), daemon=True)
+        p.start()
+        send.close()                                        # the parent keeps only the receiving end: EOF = the worker is gone
+        self.inboxes[wid], self.procs[wid], self.results[wid] = q, p, recv
+
+    def _poll(self, timeout):
+        """messages that arrived within `timeout` seconds, as (worker id, message); raises if a worker died"""
+        from multiprocessing.connection import wait
+        out = []
+        for conn in wait(self.results, timeout):
+            wid = self.results.index(conn)
+            try:
+                out.append((wid, conn.recv()))
+            except (EOFError, OSError):
+                raise RuntimeError("scheduler worker %d (%s) died (exit code %s)" % (wid, self.devices[wid], self.procs[wid].exitcode))
+        return out
 
     def put_dataset(self, X, y):
         key = self._nkeys
@@ -75,27 +93,12 @@ class RunScheduler(object):
         self._datasets[key] = (X, y)
         for q in self.inboxes:
             q.put(('dataset', key, X, y))
-        acks = 0
-        while acks < len(self.inboxes):
-            if self._get()[0] == 'ack':                     # (late results of a failed run() may still be in the queue)
-                acks += 1
+        pending = set(range(len(self.inboxes)))
+        while pending:
+            for wid, msg in self._poll(5.0):
+                if msg[0] == 'ack' and msg[1] == key:       # (acks of datasets re-sent to a replaced worker carry older keys)
+                    pending.discard(wid)
         return key
-
-    def _get(self, timeout=None):
-        import time
-        t0 = time.time()
-        while True:
-            try:
-                msg = self.outbox.get(timeout=1.0 if timeout else 5.0)
-                if msg[0] == 'ack' and len(msg) == 3:
-                    return msg
-                return msg
-            except Exception:                               # queue.Empty
-                dead = [i for i, p in enumerate(self.procs) if p.exitcode not in (None, 0)]
-                if dead:
-                    raise RuntimeError("scheduler worker(s) %s died" % dead)
-                if timeout and time.time() - t0 >= timeout:
-                    raise TimeoutError()
 
     def run(self, jobs, job_timeout=None):
         """Greedy dispatch: every idle worker takes the next job; results come back in job order.
@@ -103,12 +106,13 @@ class RunScheduler(object):
         Every message carries the id of the run() that issued it, so results of an earlier, failed run that arrive late are
         ignored.  On a failed job the jobs still in flight are waited for (their workers stay usable) before the error is
         raised.  job_timeout (seconds, optional): a job that takes longer has its worker terminated and replaced by a fresh
-        process, and counts as failed."""
+        process with a fresh job queue and result pipe (nothing the old process wrote can arrive any more), and counts as
+        failed."""
         import time
         jobs = list(jobs)
         results = [None] * len(jobs)
         self.assignments = []
-        self._run_id = getattr(self, '_run_id', 0) + 1
+        self._run_id += 1
         rid = self._run_id
         nxt, failure = 0, None
         idle = list(range(len(self.inboxes)))
@@ -120,18 +124,15 @@ class RunScheduler(object):
                 self.assignments.append((nxt, w))
                 started[w] = (nxt, time.time())
                 nxt += 1
-            try:
-                msg = self._get(timeout=1.0 if job_timeout else None)
-            except TimeoutError:
-                msg = None
-            if msg is not None and msg[0] in ('done', 'fail') and msg[2] == rid:
-                w = msg[1]
-                started.pop(w, None)
+            for w, msg in self._poll(1.0 if job_timeout else 5.0):
+                if msg[0] not in ('done', 'fail') or msg[1] != rid or w not in started:
+                    continue
+                started.pop(w)
                 idle.append(w)
                 if msg[0] == 'done':
-                    results[msg[3]] = msg[4]
+                    results[msg[2]] = msg[3]
                 elif failure is None:
-                    failure = "job %d failed on worker %d (%s):\n%s" % (msg[3], w, self.devices[w], msg[4])
+                    failure = "job %d failed on worker %d (%s):\n%s" % (msg[2], w, self.devices[w], msg[3])
             if job_timeout:
                 for w, (idx, t0) in list(started.items()):
                     if time.time() - t0 > job_timeout:
@@ -150,13 +151,10 @@ class RunScheduler(object):
         if p.is_alive():
             p.terminate()
         p.join(timeout=10)
-        q = self._ctx.Queue()
-        q.cancel_join_thread()
-        np_ = self._ctx.Process(target=_worker, args=(w, self.devices[w], self._runner, q, self.outbox), daemon=True)
-        np_.start()
-        self.inboxes[w], self.procs[w] = q, np_
+        self.results[w].close()
+        self._spawn(w)
         for key, (X, y) in self._datasets.items():
-            q.put(('dataset', key, X, y))
+            self.inboxes[w].put(('dataset', key, X, y))
 
     def close(self):
         for q, p in zip(self.inboxes, self.procs):
@@ -166,7 +164,9 @@ class RunScheduler(object):
             p.join(timeout=30)
             if p.is_alive():
                 p.terminate()
-        self.inboxes, self.procs = [], []
+        for c in self.results:
+            c.close()
+        self.inboxes, self.procs, self.results = [], [], []
 
     def __enter__(self):
         return self

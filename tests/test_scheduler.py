@@ -78,6 +78,22 @@ def test_scheduler_survives_a_failed_run_and_a_hung_job():
             sched.run(hung, job_timeout=2.0)
         out = sched.run(jobs)                                   # the replaced worker got the dataset again
         np.testing.assert_allclose([o[0] for o in out], want, rtol=0, atol=0)
+        # a second data set after the replacement: the fresh worker's acknowledgement of the RE-SENT first data set must not be
+        # counted for the new key (each worker has its own result pipe, acknowledgements carry the key)
+        X2, y2 = rs.randn(120, 5), rs.randint(0, 6, size=120)
+        key2 = sched.put_dataset(X2, y2)
+        jobs2 = _jobs(5, key2)
+        out = sched.run(jobs2)
+        np.testing.assert_allclose([o[0] for o in out], [stub_training(j, {key2: (X2, y2)}, 'cpu')[0] for j in jobs2], rtol=0, atol=0)
+        # a worker process that dies (here: killed from outside) is reported, not waited for
+        died = [dict(j) for j in jobs[:2]]
+        died[0]['sleep'] = 30.0
+        import threading
+        killer = threading.Timer(1.0, lambda: [p.kill() for p in sched.procs])
+        killer.start()
+        with pytest.raises(RuntimeError, match="died"):
+            sched.run(died)
+        killer.cancel()
 
 
 def test_scheduled_table1_prints_the_reference_lines(capsys):
