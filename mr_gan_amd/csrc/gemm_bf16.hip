@@ -633,6 +633,9 @@ static int launch_kc_tile(const GemmArgs& g, hipStream_t s) {
         // long reductions into a narrow output (D2 forward: K = 1024, N = 512): three 64x128 blocks per CU with a
         // 2-stage ring hide the k-loop latency better than two 128x128 blocks (20.7 vs 21.7 us)
         if (EPI == EPI_FWD && cfg == 7 && g.K >= 1024 && g.K < 2048 && g.N <= 512) cfg = 5;
+        // ... and with exactly one 128x128 tile per CU (D2 forward over the two segments of the G sub-step) the 8-wave tile
+        // beats two 64x128 blocks per CU: 13.9 vs 15.0 us (scripts/gemm_bench.py, KC_CFG sweep)
+        if (EPI == EPI_FWD && cfg == 0 && g.K >= 1024 && g.K < 2048 && t128 >= 256 && (g.N % 128) == 0) cfg = 7;
         // launches with at most one 64x128 tile per CU (the one-segment products of the G sub-step, small batches): 64x64 tiles
         // put twice as many blocks on the chip -- dX through D1 11.5 -> 9.7 us, d(BatchNorm output) 11.0 -> 8.5, G2 forward of one
         // segment 8.6 -> 7.4; with two tiles per CU already (two-segment launches) the smaller tile loses (10.5 -> 12.4)
