@@ -345,7 +345,9 @@ int layout(mrgan_handle* h, char* base, size_t* bytes_out) {
     h->bnb_blocks = stat_row_blocks(B);
     h->db1g_part = a.take<float>((size_t)h->bnb_blocks * N1p);
     // the tail D3..D5 + head as chain launches: bf16, A image <= 512 columns, outputs <= 256 columns
-    h->chain_ok = h->bf16 && !h->fp8 && h->d[2].Kp <= CH_KMAX && h->d[2].Np <= CH_PW && h->d[3].Np <= CH_PW && h->d[4].Np <= CH_PW;
+    // (every reduction of a chain needs two k-tiles: the weight stream keeps two tiles in flight)
+    h->chain_ok = h->bf16 && !h->fp8 && h->d[2].Kp <= CH_KMAX && h->d[2].Np <= CH_PW && h->d[3].Np <= CH_PW && h->d[4].Np <= CH_PW &&
+                  std::min(std::min(h->d[2].Kp, h->d[2].Np), std::min(h->d[3].Np, h->d[4].Np)) >= 128;
     h->use_chain = h->chain_ok;
     // bf16 / fp8 engines whose feature layer is wider than the chain's 256 columns (the wide stack) run the loss head of the D
     // sub-step on the matrix cores too (64-row blocks, as the chain's)
