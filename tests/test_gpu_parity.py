@@ -577,6 +577,9 @@ def test_narrow_stack_bf16_matches_bf16_mirror():
     #  activation is a larger share of the gradient -- the mirror moves from fp64 by the same amount, and the mirror bound holds)
     _grad_parity(72, 132, 1, 'bf16', tol=3e-3, tol_loss=5e-4, d_hidden=(200, 100, 64, 100, 64), g_hidden=(64, 100), eval_first=False,
                  loose=(0.98, 0.95, 0.3))
+    # 128-column tail: the shortest reductions the chain accepts (exactly two k-tiles per product, D3 .. D5 and their dX products)
+    _grad_parity(72, 132, 1, 'bf16', tol=3e-3, tol_loss=5e-4, d_hidden=(200, 128, 128, 128, 128), g_hidden=(128, 128), eval_first=False,
+                 loose=(0.98, 0.95, 0.3))
 
 
 def test_wide_stack_bf16_matches_bf16_mirror():
