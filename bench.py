@@ -413,26 +413,40 @@ def main():
     # HBM bytes per launch from the PMC summary under profiles/ (scripts/traffic.sh: separate --pmc passes, gfx950 FETCH_SIZE
     # correction applied there), keyed by the full instantiation name.  The summary carries the hash of the kernel sources it
     # was measured on: a summary of other sources is not evidence for this build and gives null.
-    traffic, step_traffic = None, None
+    traffic, step_traffic, traffic_src = None, None, None
     tfile = os.path.join(ROOT, "profiles", "r03_traffic.json")
     if world == 1 and not args.hidden and args.dtype == "bf16" and B == 4096 and D == 512 and os.path.exists(tfile):
         tj = json.load(open(tfile))
         if tj.get("source_sha") == source_sha():
-            rows = tj.get("kernels", {})
+            raw = tj.get("kernels", {})
+
+            def row_of(k):
+                # the library books a launch under the name it gives the instantiation; rocprofv3 prints the demangled (or, for
+                # the templates on the element type, the mangled) symbol: "chain_kernel<0>" is "chain_kernel<0, 2>" there (the
+                # rows-per-block parameter), "stage_kernel" is "_ZN5mrgan...12stage_kernelIDF16bEEv..."
+                if k in raw:
+                    return raw[k]
+                stem = k[:-1] + "," if k.endswith(">") else None
+                hits = [v for n, v in raw.items() if (stem and n.startswith(stem)) or (not stem and ("%d%s" % (len(k), k)) in n)]
+                return hits[0] if len(hits) == 1 else None
+            rows = {k: row_of(k) for k in prof}
             src = {"source": "profiles/r03_traffic.json", "source_sha": tj.get("source_sha"), "measured_at_commit": tj.get("commit")}
-            if dom in rows:
-                traffic = dict(hbm_bytes_per_launch=round(rows[dom]["hbm_bytes_per_launch"]), **src)
-            if all(k in rows for k in prof):
-                step_traffic = dict(hbm_bytes_per_step=round(sum(rows[k]["hbm_bytes_per_launch"] * v[1] / P for k, v in prof.items())), **src)
+            traffic_src = src
+            if rows.get(dom):
+                traffic = round(rows[dom]["hbm_bytes_per_launch"])
+            if all(rows.values()):
+                step_traffic = round(sum(rows[k]["hbm_bytes_per_launch"] * v[1] / P for k, v in prof.items()))
     dom_line = line(*prof[dom], peak=peak_of(dom))
-    dom_line.update({"kernel": dom, "traffic": traffic, "avg_launch_us": round(1e3 * prof[dom][0] / max(prof[dom][1], 1), 2)})
+    # traffic: HBM (fabric) bytes per launch of the dominant kernel / per step for the headline, numbers or null; where they come from
+    # goes into traffic_source
+    dom_line.update({"kernel": dom, "traffic": traffic, "traffic_unit": "bytes per launch", "avg_launch_us": round(1e3 * prof[dom][0] / max(prof[dom][1], 1), 2)})
     step_tf = fl["total"] / (elapsed / args.steps) / 1e12
     alg_bytes = sum(v[3] for v in prof.values()) / P
     # headline: the WHOLE step against the MFMA roof (650 FLOP per algorithmic byte, MFMA side), with the dominant
     # kernel's own line beside it
     roofline = {
         "bound": "mfma", "achieved": round(step_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(step_tf / peak, 4),
-        "traffic": step_traffic,
+        "traffic": step_traffic, "traffic_unit": "bytes per step (all kernels of the step)", "traffic_source": traffic_src,
         "scope": "whole (D, G) step: %.2f algorithmic GFLOP (SURVEY.md 8d: 2 FLOP per MAC, GEMMs only, unpadded shapes) over the median timed step"
                  % (fl["total"] / 1e9),
         "algorithmic_mb_per_step": round(alg_bytes / 1e6, 1),
