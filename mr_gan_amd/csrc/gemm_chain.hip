@@ -1188,12 +1188,7 @@ int launch_head_wide(const HeadWideArgs& a, hipStream_t s) {
     if ((long)h.rows * h.ldf * 2 >= (1L << 31)) return -3;
     const bool q8 = h.q8_slot != nullptr;
     if (q8 ? !(h.q8 || h.q8t) : !h.dpre) return -3;
-    static DeviceOnce attr;
-    if (attr.first()) {
-        if (hipFuncSetAttribute((const void*)head_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS) != hipSuccess) return -2;
-        if (hipFuncSetAttribute((const void*)head_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS) != hipSuccess) return -2;
-        attr.mark();
-    }
+    // (the dynamic-LDS limit of both instantiations is raised by chain_init_attributes, outside any stream capture)
     const dim3 grid((h.rows + CH_ROWS - 1) / CH_ROWS, h.nseg), block(CH_THREADS);
     if (q8) MRGAN_LAUNCH((head_wide_kernel<true>), grid, block, HW_LDS, s, a);
     else MRGAN_LAUNCH((head_wide_kernel<false>), grid, block, HW_LDS, s, a);
@@ -1206,6 +1201,8 @@ int chain_init_attributes() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GBWD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(64));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GFWD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(32));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)chain_kernel<CH_V_GBWD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(32));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS);
     return e == hipSuccess ? 0 : -2;
 }
 
