@@ -37,5 +37,5 @@ for name, op, m, n, k, nb, sp in SHAPES:
     row = "%-22s %8.2f " % (name, gf)
     for b in bits:
         us = E.debug_gemm_time(op, m, n, k, nb, sp, reps=30, ablate=b, kc_cfg=int(os.environ.get('KC_CFG', '-1')))
-        row += "%8.1f /%6.0f   " % (us, gf / us * 1e-3 * 1e3)
+        row += "%8.1f /%6.0f   " % (us, gf / us * 1e3)
     print(row)
